@@ -1,0 +1,305 @@
+/*
+ * csic_oracle.c -- CPU restatement of the reference pixel pipeline (see csic_oracle.h).
+ * TEST INFRASTRUCTURE ONLY; never linked into, loaded by, or called from the product path.
+ *
+ * Two independent forms of the same semantics live here on purpose:
+ *   orc_process_stream  -- explicit per-stage state machines (counters, held chroma),
+ *                          wired in op[] order like the RTL top level;
+ *   orc_process_closed  -- the per-output-pixel gather of SURVEY.md Appendix A.3/A.4.
+ * tests/test_oracle_forms.py requires them to agree on random shapes and all six orders.
+ *
+ * Citations are relative to /root/reference/.
+ */
+#include "csic_oracle.h"
+
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* per-pixel arithmetic                                                       */
+/* ------------------------------------------------------------------------- */
+
+static inline int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+/* floor(x / 256) without relying on the implementation-defined >> of negatives */
+static inline int floor_div256(int x) { return x >= 0 ? (x >> 8) : -((-x + 255) >> 8); }
+
+/* Scala Int '/' == C '/' : truncation toward zero */
+static inline int trunc_div256(int x) { return x / 256; }
+
+/* RGB2YCbCr.scala:33-35 (products), :55-65 (bias, floor shift, +128 offset), :37-47 (clamp)
+ * ReferenceModel.scala:10-17 (same, '>> 8');  RGB2YCbCr.scala:100-118 (same, '/ 256'). */
+void orc_rgb2ycbcr(int r, int g, int b, int rounding, int *y, int *cb, int *cr)
+{
+    int yi  =  77 * r + 150 * g +  29 * b;
+    int cbi = -43 * r -  85 * g + 128 * b;
+    int cri = 128 * r - 107 * g -  21 * b;
+    if (rounding == ORC_ROUND_TRUNC_SW) {
+        *y  = clamp255(trunc_div256(yi  + 128));
+        *cb = clamp255(trunc_div256(cbi + 128) + 128);
+        *cr = clamp255(trunc_div256(cri + 128) + 128);
+    } else {
+        *y  = clamp255(floor_div256(yi  + 128));
+        *cb = clamp255(floor_div256(cbi + 128) + 128);
+        *cr = clamp255(floor_div256(cri + 128) + 128);
+    }
+}
+
+/* YCbCr2RGB.scala:17-26 == RGB2YCbCr.scala:123-132.  c = y (NOT y-16): the pair is lossy. */
+void orc_ycbcr2rgb(int y, int cb, int cr, int *r, int *g, int *b)
+{
+    int c = y, d = cb - 128, e = cr - 128;
+    *r = clamp255(floor_div256(298 * c + 409 * e + 128));
+    *g = clamp255(floor_div256(298 * c - 100 * d - 208 * e + 128));
+    *b = clamp255(floor_div256(298 * c + 516 * d + 128));
+}
+
+/* ColorQuantizer.scala:29-31,42-44 == ColorQuantizerSpec.scala:29-34 */
+void orc_quantize(int y, int cb, int cr, int yb, int cbb, int crb, int *yq, int *cbq, int *crq)
+{
+    int sy = 8 - yb, scb = 8 - cbb, scr = 8 - crb;
+    *yq  = (y  >> sy)  << sy;
+    *cbq = (cb >> scb) << scb;
+    *crq = (cr >> scr) << scr;
+}
+
+/* ------------------------------------------------------------------------- */
+/* validation                                                                  */
+/* ------------------------------------------------------------------------- */
+
+/* ImageProcessor.scala:22-28, ChromaSubsampler.scala:13-18, SpatialDownsampler.scala:7-8,
+ * ColorQuantizer.scala:12-15, ImageCompressorTop.scala:27-31.  (The divisibility rule of
+ * ImageProcessor.scala:25 is a property of ImageProcessorParams only and is checked by the
+ * host mirror, not here.) */
+int orc_validate(const orc_params *p)
+{
+    if (!p) return -1;
+    if (p->width <= 0 || p->height <= 0) return -2;
+    if (!(p->factor == 1 || p->factor == 2 || p->factor == 4 || p->factor == 8)) return -3;
+    if (!(p->chroma_a == 4 || p->chroma_a == 2 || p->chroma_a == 1)) return -4;
+    if (!(p->chroma_b == p->chroma_a || p->chroma_b == 0)) return -5;
+    if (p->y_bits < 1 || p->y_bits > 8 || p->cb_bits < 1 || p->cb_bits > 8 ||
+        p->cr_bits < 1 || p->cr_bits > 8) return -6;
+    int seen[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+        if (p->op[k] < 1 || p->op[k] > 3) return -7;
+        if (seen[p->op[k]]++) return -7;
+    }
+    if (p->rounding != ORC_ROUND_FLOOR_HW && p->rounding != ORC_ROUND_TRUNC_SW) return -8;
+    if (p->out_format != ORC_FMT_ARGB && p->out_format != ORC_FMT_YCC) return -9;
+    return 0;
+}
+
+/* SpatialDownsampler emits one pixel per (row % f == 0, col % f == 0):
+ * ceil(W/f) x ceil(H/f); KAT 5x3,f=2 -> 6 pixels (SpatialDownsamplerSpec.scala:120-122). */
+void orc_out_dims(const orc_params *p, int32_t *wo, int32_t *ho)
+{
+    *wo = (p->width  + p->factor - 1) / p->factor;
+    *ho = (p->height + p->factor - 1) / p->factor;
+}
+
+/* ------------------------------------------------------------------------- */
+/* streaming form: explicit stage state machines                              */
+/* ------------------------------------------------------------------------- */
+
+typedef struct { int y, cb, cr; } ycc_t;
+
+typedef struct {             /* ChromaSubsampler.scala:26-27,34-38 */
+    int W, H, h, v;
+    int pixel_counter, line_counter;
+    int last_cb, last_cr;    /* RegInit(0.U) */
+} chroma_state;
+
+typedef struct {             /* SpatialDownsampler.scala:17-18 */
+    int W, H, f;
+    int col, row;
+} spatial_state;
+
+static void chroma_init(chroma_state *s, int W, int H, int a, int b)
+{
+    s->W = W; s->H = H;
+    s->h = 4 / a;                          /* ChromaSubsampler.scala:26 */
+    s->v = (b == 0 && a != 0) ? 2 : 1;     /* ChromaSubsampler.scala:27 */
+    s->pixel_counter = 0; s->line_counter = 0;
+    s->last_cb = 0; s->last_cr = 0;
+}
+
+/* one fire of ChromaSubsampler.scala:47-65 (+ Counter wrap :37-38) */
+static ycc_t chroma_step(chroma_state *s, ycc_t in)
+{
+    ycc_t out;
+    out.y = in.y;                                            /* :48 */
+    int sample_h = (s->pixel_counter % s->h) == 0;          /* :52 */
+    int sample_v = (s->line_counter  % s->v) == 0;          /* :53 */
+    if (sample_h && sample_v) {                              /* :57-61 */
+        out.cb = in.cb; out.cr = in.cr;
+        s->last_cb = in.cb; s->last_cr = in.cr;
+    } else {                                                 /* :62-65 */
+        out.cb = s->last_cb; out.cr = s->last_cr;
+    }
+    if (++s->pixel_counter == s->W) {                        /* Counter(fire, imageWidth) */
+        s->pixel_counter = 0;
+        if (++s->line_counter == s->H) s->line_counter = 0;  /* Counter(fire && wrap, imageHeight) */
+    }
+    return out;
+}
+
+static void spatial_init(spatial_state *s, int W, int H, int f)
+{
+    s->W = W; s->H = H; s->f = f; s->col = 0; s->row = 0;
+}
+
+/* one fire of SpatialDownsampler.scala:20-55; returns 1 if the pixel is passed on */
+static int spatial_step(spatial_state *s)
+{
+    int m = s->f - 1;
+    int do_sample = ((s->col & m) == 0) && ((s->row & m) == 0);  /* :33-45 */
+    if (s->col == s->W - 1) {                                     /* :21-31 */
+        s->col = 0;
+        s->row = (s->row == s->H - 1) ? 0 : s->row + 1;
+    } else {
+        s->col += 1;
+    }
+    return do_sample;
+}
+
+static inline uint32_t pack_out(const orc_params *p, ycc_t v)
+{
+    if (p->out_format == ORC_FMT_YCC)
+        return (uint32_t)v.y | ((uint32_t)v.cb << 8) | ((uint32_t)v.cr << 16);
+    int r, g, b;
+    orc_ycbcr2rgb(v.y, v.cb, v.cr, &r, &g, &b);   /* ImageCompressorTopApp.scala:118 */
+    return 0xFF000000u | ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b; /* :139 */
+}
+
+long orc_process_stream(const orc_params *p, const uint32_t *in, uint32_t *out)
+{
+    if (orc_validate(p) != 0) return -1;
+    const int W = p->width, H = p->height;
+    chroma_state  cs; chroma_init(&cs, W, H, p->chroma_a, p->chroma_b);   /* full W,H: ImageCompressorTop.scala:52-58 */
+    spatial_state ss; spatial_init(&ss, W, H, p->factor);                 /* full W,H: ImageCompressorTop.scala:44 */
+    long n_out = 0;
+    const long n_in = (long)W * H;
+    for (long i = 0; i < n_in; ++i) {
+        uint32_t px = in[i];
+        int b = px & 0xFF, g = (px >> 8) & 0xFF, r = (px >> 16) & 0xFF;   /* alpha ignored: ImageProcessorModel.scala:48 */
+        ycc_t v;
+        orc_rgb2ycbcr(r, g, b, p->rounding, &v.y, &v.cb, &v.cr);           /* toYC, ImageCompressorTop.scala:80-81 */
+        int alive = 1;
+        for (int k = 0; k < 3 && alive; ++k) {                             /* op1 -> op2 -> op3, :83-114 */
+            switch (p->op[k]) {
+            case ORC_OP_SPATIAL: alive = spatial_step(&ss); break;
+            case ORC_OP_QUANT:
+                orc_quantize(v.y, v.cb, v.cr, p->y_bits, p->cb_bits, p->cr_bits, &v.y, &v.cb, &v.cr);
+                break;
+            case ORC_OP_CHROMA:  v = chroma_step(&cs, v); break;
+            default: return -1;
+            }
+        }
+        if (alive) out[n_out++] = pack_out(p, v);
+    }
+    return n_out;
+}
+
+/* ------------------------------------------------------------------------- */
+/* closed form                                                                 */
+/* ------------------------------------------------------------------------- */
+
+static int spatial_before_chroma(const orc_params *p)
+{
+    int is = -1, ic = -1;
+    for (int k = 0; k < 3; ++k) {
+        if (p->op[k] == ORC_OP_SPATIAL) is = k;
+        if (p->op[k] == ORC_OP_CHROMA)  ic = k;
+    }
+    return is < ic;
+}
+
+long orc_process_closed_rows(const orc_params *p, const uint32_t *in, uint32_t *out,
+                             int32_t ro0, int32_t ro1)
+{
+    if (orc_validate(p) != 0) return -1;
+    const long W = p->width;
+    const int f = p->factor;
+    const int h = 4 / p->chroma_a;
+    const int v = (p->chroma_b == 0) ? 2 : 1;
+    int32_t wo, ho; orc_out_dims(p, &wo, &ho);
+    if (ro0 < 0 || ro1 > ho || ro0 > ro1) return -1;
+    const int s_first = spatial_before_chroma(p);
+    long n = 0;
+    for (long ro = ro0; ro < ro1; ++ro) {
+        for (long co = 0; co < wo; ++co) {
+            long y_idx = (ro * f) * W + co * f;       /* pixel that supplies Y */
+            long c_idx;                               /* pixel that supplies Cb,Cr */
+            if (!s_first) {
+                /* chroma runs on the full raster: Appendix A.3 with Wm = W on image coordinates */
+                long r = ro * f, c = co * f;
+                if (r % v == 0) c_idx = r * W + (c - c % h);
+                else            c_idx = (r - 1) * W + ((W - 1) / h) * h;
+            } else {
+                /* chroma runs on the decimated stream but still wraps its column counter at the
+                 * full width W (ImageCompressorTop.scala:52-58): Appendix A.4 */
+                long j = ro * wo + co;
+                long c = j % W, r = j / W;
+                long src = (r % v == 0) ? (j - c % h) : ((r - 1) * W + ((W - 1) / h) * h);
+                long sro = src / wo, sco = src % wo;
+                c_idx = (sro * f) * W + sco * f;
+            }
+            uint32_t py = in[y_idx], pc = in[c_idx];
+            ycc_t a, c2;
+            orc_rgb2ycbcr((py >> 16) & 0xFF, (py >> 8) & 0xFF, py & 0xFF, p->rounding, &a.y, &a.cb, &a.cr);
+            orc_rgb2ycbcr((pc >> 16) & 0xFF, (pc >> 8) & 0xFF, pc & 0xFF, p->rounding, &c2.y, &c2.cb, &c2.cr);
+            a.cb = c2.cb; a.cr = c2.cr;
+            orc_quantize(a.y, a.cb, a.cr, p->y_bits, p->cb_bits, p->cr_bits, &a.y, &a.cb, &a.cr);
+            out[ro * wo + co] = pack_out(p, a);
+            ++n;
+        }
+    }
+    return n;
+}
+
+long orc_process_closed(const orc_params *p, const uint32_t *in, uint32_t *out)
+{
+    if (orc_validate(p) != 0) return -1;
+    int32_t wo, ho; orc_out_dims(p, &wo, &ho);
+    return orc_process_closed_rows(p, in, out, 0, ho);
+}
+
+/* ------------------------------------------------------------------------- */
+/* per-stage helpers for the KAT tests                                         */
+/* ------------------------------------------------------------------------- */
+
+void orc_chroma_stream(const uint8_t *ycc_in, uint8_t *ycc_out, long n, int W, int H, int a, int b)
+{
+    chroma_state cs; chroma_init(&cs, W, H, a, b);
+    for (long i = 0; i < n; ++i) {
+        ycc_t v = { ycc_in[3 * i], ycc_in[3 * i + 1], ycc_in[3 * i + 2] };
+        v = chroma_step(&cs, v);
+        ycc_out[3 * i] = (uint8_t)v.y; ycc_out[3 * i + 1] = (uint8_t)v.cb; ycc_out[3 * i + 2] = (uint8_t)v.cr;
+    }
+}
+
+long orc_spatial_indices(int W, int H, int f, int64_t *idx_out)
+{
+    spatial_state ss; spatial_init(&ss, W, H, f);
+    long n = 0;
+    for (long i = 0; i < (long)W * H; ++i)
+        if (spatial_step(&ss)) idx_out[n++] = i;
+    return n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* synthetic frames                                                            */
+/* ------------------------------------------------------------------------- */
+
+static inline uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+
+void orc_synth_frame(uint32_t *dst, int64_t npix, int64_t first_index, uint32_t seed)
+{
+    const uint32_t salt = seed * 0x9E3779B9u;
+    for (int64_t i = 0; i < npix; ++i)
+        dst[i] = 0xFF000000u | (fmix32((uint32_t)(first_index + i) + salt) & 0x00FFFFFFu);
+}
