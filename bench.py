@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the fused pixel pipeline on MI355X.
+
+Metric (BASELINE.json): input Mpixels/s end to end (RGB -> YCbCr -> 4:2:0 -> reconstruct), device
+resident packed ARGB in HBM -> reconstructed packed ARGB in HBM, plus the fraction of the HBM roofline.
+
+Workload at N=1: BASELINE.json configs[3] ("cfg 4" of SURVEY.md 8): synthetic 8192x8192 RGB, 4:2:0,
+sf=2, no quantisation, order chroma->spatial->quant.  One "step" = one frame = one kernel launch.
+At N>1 (one process per GPU, launched by torch.distributed.run) the frame is row-striped: the global
+frame is 8192 wide and 8192*N tall, every rank owns one aligned 8192x8192 stripe (weak scaling; the
+stripes are independent images -- csic_stripe_rows -- so there is NO data-path collective; RCCL is
+used only for the barrier and the max-over-ranks of the elapsed time).  `--scaling strong` splits one
+8192x8192 frame N ways instead.
+
+Frames rotate through a ring of distinct device buffers larger than the 256 MiB Infinity Cache so the
+kernel streams from HBM, not from L3.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    # name: (W, H, a, b, (bits), f, frames_per_step)
+    "cfg2": (128, 128, 2, 2, (3, 3, 2), 1, 1),
+    "cfg3": (512, 512, 2, 0, (3, 3, 2), 2, 1),
+    "cfg4": (8192, 8192, 2, 0, (8, 8, 8), 2, 1),
+    "cfg5": (3840, 2160, 2, 0, (3, 3, 2), 4, 64),
+    "8k_444_f1": (8192, 8192, 4, 4, (8, 8, 8), 1, 1),
+    "8k_420_f1": (8192, 8192, 2, 0, (3, 3, 2), 1, 1),
+}
+CSQ = (3, 1, 2)
+
+
+def cpu_baseline(W, H, a, b, bits, f, budget_s=10.0):
+    """The oracle's streaming restatement (oracle/csic_oracle.c, scalar C, 1 thread) timed on this
+    host on whole frames of the same workload until ~budget_s of CPU work has been done."""
+    import numpy as np
+    from oracle import oracle as orc
+    orc.build()
+    p = orc.OracleParams(width=W, height=H, chroma_a=a, chroma_b=b, y_bits=bits[0], cb_bits=bits[1],
+                         cr_bits=bits[2], factor=f, op=CSQ)
+    frame = orc.synth_frame(W * H, 0)
+    wo, ho = orc.out_dims(p)
+    out = np.empty(wo * ho, dtype=np.uint32)
+    cp = p.c()
+    fn = orc.lib().orc_process_stream
+    u32p = C.POINTER(C.c_uint32)
+    pin, pout = frame.ctypes.data_as(u32p), out.ctypes.data_as(u32p)
+    fn(C.byref(cp), pin, pout)                                   # warm-up (page faults)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn(C.byref(cp), pin, pout)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {
+        "value": round(n * W * H / el / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+        "sample": f"{n} full {W}x{H} frames through oracle/csic_oracle.c orc_process_stream "
+                  f"(scalar C -O2, streaming state machines) in {el:.1f} s; host has {os.cpu_count()} logical cores",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
+    ap.add_argument("--variant", type=int, default=-1, help="kernel variant (CSIC_TUNE_VARIANT); -1 = library default")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--ring-mib", type=int, default=2048, help="input bytes rotated through (MiB), per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=10.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import csic_amd as csic
+    N = csic._native
+    lib = N.lib()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)            # RCCL; barrier + max-reduce only
+
+    W, H, a, b, bits, f, fps = CONFIGS[args.config]
+    # ---- this rank's stripe ---------------------------------------------------------------------
+    gH = H * world if args.scaling == "weak" else H
+    gparams = csic.make_c_params(W, gH, a, b, *bits, f, CSQ)
+    r0, nr, o0, on = (C.c_int32() for _ in range(4))
+    N.check(lib.csic_stripe_rows(C.byref(gparams), world, rank, C.byref(r0), C.byref(nr), C.byref(o0), C.byref(on)))
+    sH = nr.value
+    plan = csic.Plan(csic.make_c_params(W, sH, a, b, *bits, f, CSQ), local_rank)
+    if args.variant >= 0:
+        plan.tune(N.TUNE_VARIANT, args.variant)
+    in_px, out_px = W * sH, plan.out_width * plan.out_height
+    alg_bytes = plan.algorithmic_bytes * fps                      # per launch
+
+    # ---- ring of distinct frames, generated on the device ---------------------------------------
+    step_in_bytes = in_px * 4 * fps
+    nring = max(2, min(64, (args.ring_mib << 20) // max(step_in_bytes, 1)))
+    stream = torch.cuda.current_stream(dev)
+    sh = C.c_void_p(stream.cuda_stream)
+    ins = [torch.empty(in_px * fps, dtype=torch.int32, device=dev) for _ in range(nring)]
+    outs = [torch.empty(out_px * fps, dtype=torch.int32, device=dev) for _ in range(nring)]
+    for k, t in enumerate(ins):
+        first = (k * world + rank) * in_px * fps + r0.value * W
+        N.check(lib.csic_synth_frame_device(C.c_void_p(t.data_ptr()), t.numel(), first, 20250629, sh))
+    in_ptrs = [C.c_void_p(t.data_ptr()) for t in ins]
+    out_ptrs = [C.c_void_p(t.data_ptr()) for t in outs]
+    ph = plan._h
+    if fps == 1:
+        def step(i):
+            return lib.csic_process_device(ph, in_ptrs[i % nring], out_ptrs[i % nring], sh)
+    else:
+        def step(i):
+            return lib.csic_process_batch_device(ph, in_ptrs[i % nring], out_ptrs[i % nring], fps, sh)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        N.check(step(i))
+    barrier()
+
+    # ---- timed region: exactly K steps ----------------------------------------------------------
+    K = args.steps
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(K):
+        ev[i][0].record(stream)
+        st = step(i)
+        ev[i][1].record(stream)
+        if st != 0:
+            N.check(st)
+    ev1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-launch kernel time from HIP events on the launch stream ----------------------------
+    pair_ms = sorted(s.elapsed_time(e) for s, e in ev)
+    kern_ms_avg = sum(pair_ms) / K
+    kern_ms_med = pair_ms[K // 2]
+    region_ms = ev0.elapsed_time(ev1)
+
+    total_px = world * in_px * fps * K if args.scaling == "weak" else in_px * fps * K * world
+    value = total_px / elapsed / 1e6
+    achieved = alg_bytes / (kern_ms_avg * 1e-3) / 1e9
+
+    if rank == 0:
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                ent = tj.get(args.config, {}).get(plan.kernel_name)
+                if ent:
+                    traffic, traffic_note = ent["hbm_bytes_per_launch"], ent.get("note")
+            except Exception:
+                pass
+        line = {
+            "metric": "Mpixels/s end-to-end (RGB->YCbCr->4:2:0->reconstruct)",
+            "value": round(value, 1), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / K, 5),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: {W}x{H} ARGB, 4:{a}:{b}, bits {bits[0]}/{bits[1]}/{bits[2]}, sf={f}, "
+                            f"order chroma->spatial->quant, {fps} frame(s)/step, FLOOR_HW",
+                "stripe_rows_per_gpu": sH, "global_rows": gH, "ring_frames": nring,
+                "parallelism": f"row-stripe x{world}, no collective",
+                "kernel": plan.kernel_name,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms_avg": round(kern_ms_avg, 5), "kernel_ms_median": round(kern_ms_med, 5),
+                "launch_period_ms": round(region_ms / K, 5),
+                "timing": "HIP event pair around every launch on the launch stream (torch current stream)",
+            },
+        }
+        if traffic_note:
+            line["roofline"]["traffic_source"] = traffic_note
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(W, H, a, b, bits, f, args.cpu_budget)
+        print(json.dumps(line), flush=True)
+
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

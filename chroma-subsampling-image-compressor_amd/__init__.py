@@ -1,0 +1,16 @@
+"""MI355X-native drop-in for the pixel-stream hot path of Andurdur/Chroma-Subsampling-Image-Compressor.
+
+The compute lives in libcsic_hip.so (csrc/, hand-written HIP for gfx950) behind the C ABI of
+include/csic.h; this package is the host-side mirror of the reference's generator surface
+(ImageProcessorParams / ProcessingStep / ImageCompressorTop / ImageProcessor / ImageProcessorModel /
+ImageCompressionApp).  There is no CPU compute path in here.
+"""
+from . import _native
+from ._native import CsicRuntimeError, IllegalArgumentException
+from .params import ImageProcessorParams, PixelFormat, ProcessingStep, Rounding, make_c_params
+from .compressor import ImageCompressorTop, ImageProcessor, Plan
+
+__all__ = [
+    "CsicRuntimeError", "IllegalArgumentException", "ImageProcessorParams", "PixelFormat", "ProcessingStep",
+    "Rounding", "make_c_params", "ImageCompressorTop", "ImageProcessor", "Plan",
+]

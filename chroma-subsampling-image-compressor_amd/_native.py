@@ -1,0 +1,104 @@
+"""ctypes binding of libcsic_hip.so (include/csic.h).  No fallback: if the HIP library is missing or
+no device is visible, the failure is loud."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsic_hip.so")
+
+# csic_status (include/csic.h)
+OK = 0
+EINVAL_NULL, EINVAL_DIMS, EINVAL_FACTOR, EINVAL_CHROMA_A, EINVAL_CHROMA_B = -1, -2, -3, -4, -5
+EINVAL_BITS, EINVAL_OP_PERMUTATION, EINVAL_ROUNDING, EINVAL_FORMAT = -6, -7, -8, -9
+EINVAL_NOT_DIVISIBLE, EINVAL_SAMPLING, EINVAL_STRIPE, EINVAL_SIZE = -10, -11, -12, -13
+ENODEVICE, EHIP, ENOMEM = -20, -21, -22
+
+OP_NOOP, OP_SPATIAL, OP_QUANT, OP_CHROMA = 0, 1, 2, 3
+ROUND_FLOOR_HW, ROUND_TRUNC_SW = 0, 1
+FMT_ARGB8888, FMT_YCBCR888X = 0, 1
+TUNE_VARIANT, TUNE_FORCE_GENERIC = 1, 2
+
+
+class IllegalArgumentException(ValueError):
+    """What the reference's require()s throw at generator construction
+    (e.g. ImageProcessor.scala:22-28; tested by SpatialDownsamplerSpec.scala:147-151)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+class CsicRuntimeError(RuntimeError):
+    """HIP / device failures (CSIC_ENODEVICE, CSIC_EHIP, CSIC_ENOMEM)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+class CsicParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("chroma_a", C.c_int32), ("chroma_b", C.c_int32),
+        ("y_bits", C.c_int32), ("cb_bits", C.c_int32), ("cr_bits", C.c_int32),
+        ("factor", C.c_int32),
+        ("op", C.c_int32 * 3),
+        ("rounding", C.c_int32),
+        ("sampling", C.c_int32),
+        ("in_format", C.c_int32), ("out_format", C.c_int32),
+        ("strict_divisible", C.c_int32),
+    ]
+
+
+# every symbol include/csic.h declares, with its prototype
+PROTOTYPES = {
+    "csic_abi_version": (C.c_int, []),
+    "csic_params_default": (C.c_int, [C.POINTER(CsicParams), C.c_int32, C.c_int32]),
+    "csic_validate": (C.c_int, [C.POINTER(CsicParams)]),
+    "csic_out_dims": (C.c_int, [C.POINTER(CsicParams), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "csic_algorithmic_bytes": (C.c_int, [C.POINTER(CsicParams), C.POINTER(C.c_int64)]),
+    "csic_stripe_rows": (C.c_int, [C.POINTER(CsicParams), C.c_int32, C.c_int32] + [C.POINTER(C.c_int32)] * 4),
+    "csic_strerror": (C.c_char_p, [C.c_int]),
+    "csic_last_error": (C.c_char_p, []),
+    "csic_device_count": (C.c_int, []),
+    "csic_plan_create": (C.c_int, [C.POINTER(CsicParams), C.c_int, C.POINTER(C.c_void_p)]),
+    "csic_plan_destroy": (C.c_int, [C.c_void_p]),
+    "csic_plan_kernel_name": (C.c_char_p, [C.c_void_p]),
+    "csic_plan_tune": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "csic_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "csic_process_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "csic_process_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "csic_synth_frame_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]),
+    "csic_checksum_device": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64), C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C chroma-subsampling-image-compressor_amd/csrc`. There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            fn = getattr(L, name)            # AttributeError here == ABI drift; keep it loud
+            fn.restype, fn.argtypes = restype, argtypes
+        if L.csic_abi_version() != 1:
+            raise ImportError("libcsic_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> int:
+    """Maps negative csic_status to the exception the reference's host code would see."""
+    if status >= 0:
+        return status
+    msg = lib().csic_last_error().decode() or lib().csic_strerror(status).decode()
+    if EINVAL_SIZE <= status <= EINVAL_NULL:
+        raise IllegalArgumentException(status, "requirement failed: " + msg)
+    raise CsicRuntimeError(status, msg)

@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's generators for the hot path.
+
+ImageCompressorTop <- class ImageCompressorTop(...), ImageCompressorTop.scala:11-25 (same 11-argument
+                      list, same order, same require()s); instead of a Decoupled `io` bundle driven one
+                      pixel per simulated clock (ImageCompressorTopApp.scala:76-124) it exposes
+                      process(): one fused HIP kernel launch per frame.
+ImageProcessor     <- class ImageProcessor(p: ImageProcessorParams), ImageProcessor.scala:31-63.
+Plan               <- thin RAII wrapper of csic_plan (include/csic.h).
+
+Device memory and streams come from PyTorch (plumbing only): CUDA tensors are passed by data_ptr and
+the launch goes to torch's current stream.  numpy inputs take csic_process_host (H2D + kernel + D2H).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native as N
+from .params import (ImageProcessorParams, PixelFormat, ProcessingStep, Rounding, make_c_params)
+
+
+def _is_torch_tensor(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+class Plan:
+    """One validated parameter set bound to one HIP device (csic_plan_create / csic_plan_destroy)."""
+
+    def __init__(self, c_params: N.CsicParams, device: int = 0):
+        self._h = C.c_void_p()
+        self.c_params = c_params
+        self.device = int(device)
+        N.check(N.lib().csic_plan_create(C.byref(c_params), self.device, C.byref(self._h)))
+        wo, ho = C.c_int32(), C.c_int32()
+        N.check(N.lib().csic_out_dims(C.byref(c_params), C.byref(wo), C.byref(ho)))
+        self.width, self.height = c_params.width, c_params.height
+        self.out_width, self.out_height = wo.value, ho.value
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            N.lib().csic_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- introspection ----------------------------------------------------------------------------
+    @property
+    def kernel_name(self) -> str:
+        return N.lib().csic_plan_kernel_name(self._h).decode()
+
+    @property
+    def algorithmic_bytes(self) -> int:
+        b = C.c_int64()
+        N.check(N.lib().csic_algorithmic_bytes(C.byref(self.c_params), C.byref(b)))
+        return b.value
+
+    def tune(self, knob: int, value: int) -> None:
+        N.check(N.lib().csic_plan_tune(self._h, knob, value))
+
+    # -- compute ----------------------------------------------------------------------------------
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def process_device(self, d_in, d_out=None, nframes: int = 1):
+        """d_in: CUDA int32/uint32 tensor with nframes*W*H elements (any shape).  Returns d_out shaped
+        (Ho, Wo) or (nframes, Ho, Wo).  Asynchronous on torch's current stream."""
+        import torch
+        if not d_in.is_cuda or d_in.element_size() != 4 or not d_in.is_contiguous():
+            raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: d_in must be a contiguous 4-byte CUDA tensor")
+        if d_in.device.index != self.device:
+            raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: tensor is on a different device than the plan")
+        if d_in.numel() != nframes * self.width * self.height:
+            raise N.IllegalArgumentException(N.EINVAL_SIZE, f"requirement failed: expected {nframes * self.width * self.height} input pixels, got {d_in.numel()}")
+        shape = (self.out_height, self.out_width) if nframes == 1 else (nframes, self.out_height, self.out_width)
+        if d_out is None:
+            d_out = torch.empty(shape, dtype=d_in.dtype, device=d_in.device)
+        elif d_out.numel() != nframes * self.out_width * self.out_height or not d_out.is_contiguous() \
+                or d_out.element_size() != 4 or d_out.device != d_in.device:
+            raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: d_out has the wrong size/layout")
+        if nframes == 1:
+            st = N.lib().csic_process_device(self._h, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr()), self._stream())
+        else:
+            st = N.lib().csic_process_batch_device(self._h, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr()),
+                                                   nframes, self._stream())
+        N.check(st)
+        return d_out
+
+    def process_host(self, argb: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(argb, dtype=np.uint32).reshape(-1)
+        out = np.empty(self.out_width * self.out_height, dtype=np.uint32)
+        N.check(N.lib().csic_process_host(self._h, a.ctypes.data_as(C.c_void_p), a.size,
+                                          out.ctypes.data_as(C.c_void_p), out.size))
+        return out.reshape(self.out_height, self.out_width)
+
+    def process(self, frame):
+        return self.process_device(frame) if _is_torch_tensor(frame) else self.process_host(frame)
+
+
+class ImageCompressorTop:
+    """RGB2YCbCr -> op1 -> op2 -> op3 (-> YCbCr2RGB), parameter list of ImageCompressorTop.scala:11-25."""
+
+    def __init__(self, width: int, height: int,
+                 chroma_param_a_config: int, chroma_param_b_config: int,
+                 yTargetQuantBitsConfig: int, cbTargetQuantBitsConfig: int, crTargetQuantBitsConfig: int,
+                 downFactorConfig: int,
+                 op1Type: ProcessingStep, op2Type: ProcessingStep, op3Type: ProcessingStep,
+                 *, rounding: Rounding = Rounding.FLOOR_HW, device: int = 0):
+        self.width, self.height = width, height
+        self.ops = (ProcessingStep(op1Type), ProcessingStep(op2Type), ProcessingStep(op3Type))
+        self.rounding, self.device = Rounding(rounding), device
+        self._args = (width, height, chroma_param_a_config, chroma_param_b_config, yTargetQuantBitsConfig,
+                      cbTargetQuantBitsConfig, crTargetQuantBitsConfig, downFactorConfig, self.ops)
+        # construction-time require()s, before any device is touched (ImageCompressorTop.scala:27-31 etc.)
+        N.check(N.lib().csic_validate(C.byref(self._c_params(PixelFormat.ARGB8888))))
+        self._plans = {}
+
+    def _c_params(self, fmt: PixelFormat) -> N.CsicParams:
+        return make_c_params(*self._args, rounding=self.rounding, out_format=fmt, strict_divisible=False)
+
+    def plan(self, fmt: PixelFormat = PixelFormat.ARGB8888) -> Plan:
+        if fmt not in self._plans:
+            self._plans[fmt] = Plan(self._c_params(fmt), self.device)
+        return self._plans[fmt]
+
+    @property
+    def out_dims(self) -> Tuple[int, int]:
+        """(out_width, out_height) = ceil(W/f), ceil(H/f): what SpatialDownsampler emits."""
+        wo, ho = C.c_int32(), C.c_int32()
+        N.check(N.lib().csic_out_dims(C.byref(self._c_params(PixelFormat.ARGB8888)), C.byref(wo), C.byref(ho)))
+        return wo.value, ho.value
+
+    def process(self, argb):
+        """ARGB frame in -> reconstructed ARGB frame out (what ImageCompressionApp writes to the PNG:
+        the DUT's YCbCr output put through YCbCrUtils.ycbcr2rgb, ImageCompressorTopApp.scala:118)."""
+        return self.plan(PixelFormat.ARGB8888).process(argb)
+
+    def processYCbCr(self, argb):
+        """ARGB frame in -> the PixelYCbCrBundle stream io.out carries (byte0=Y, byte1=Cb, byte2=Cr)."""
+        return self.plan(PixelFormat.YCBCR888X).process(argb)
+
+    def close(self) -> None:
+        for p in self._plans.values():
+            p.close()
+        self._plans = {}
+
+
+class ImageProcessor(ImageCompressorTop):
+    """Fixed pipeline RGB2YCbCr -> ChromaSubsampler -> SpatialDownsampler, no quantiser
+    (ImageProcessor.scala:42-62)."""
+
+    def __init__(self, p: ImageProcessorParams, *, rounding: Rounding = Rounding.FLOOR_HW, device: int = 0):
+        if not isinstance(p, ImageProcessorParams):
+            raise TypeError("ImageProcessor takes an ImageProcessorParams")
+        self.p = p
+        super().__init__(p.width, p.height, p.chromaParamA, p.chromaParamB, 8, 8, 8, p.factor,
+                         ProcessingStep.ChromaSubsampling, ProcessingStep.SpatialSampling,
+                         ProcessingStep.ColorQuantization, rounding=rounding, device=device)

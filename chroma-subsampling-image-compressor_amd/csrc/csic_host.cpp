@@ -1,0 +1,217 @@
+// csic_host.cpp -- host-only half of the C ABI: parameter validation (the reference's require()s),
+// geometry, the algorithmic-byte model and the row-stripe partition.  No HIP calls in this file, so
+// every function here works on a machine without a GPU.
+//
+// Citations are relative to /root/reference/.
+#include "csic_internal.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace csic {
+
+static thread_local char g_last_error[512] = "";
+
+int set_error(int status, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof g_last_error, fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+void clear_error() { g_last_error[0] = '\0'; }
+
+static int validate_impl(const csic_params *p)
+{
+    if (!p) return set_error(CSIC_EINVAL_NULL, "params is NULL");
+    // ImageProcessor.scala:22-23 "width/height must be positive"
+    if (p->width <= 0 || p->height <= 0)
+        return set_error(CSIC_EINVAL_DIMS, "width and height must be positive. Got %dx%d", p->width, p->height);
+    // pixel indices are 32-bit in the kernels
+    if ((int64_t)p->width * (int64_t)p->height >= (int64_t)1 << 31)
+        return set_error(CSIC_EINVAL_DIMS, "width*height must be < 2^31. Got %dx%d", p->width, p->height);
+    // ImageProcessor.scala:24, SpatialDownsampler.scala:8 "Factor must be 1, 2, 4, or 8"
+    if (!(p->factor == 1 || p->factor == 2 || p->factor == 4 || p->factor == 8))
+        return set_error(CSIC_EINVAL_FACTOR, "factor must be 1, 2, 4, or 8. Got %d", p->factor);
+    // ImageProcessor.scala:27, ChromaSubsampler.scala:17
+    if (!(p->chroma_a == 4 || p->chroma_a == 2 || p->chroma_a == 1))
+        return set_error(CSIC_EINVAL_CHROMA_A, "chroma_a must be 4, 2, or 1. Got %d", p->chroma_a);
+    // ImageProcessor.scala:28, ChromaSubsampler.scala:18
+    if (!(p->chroma_b == p->chroma_a || p->chroma_b == 0))
+        return set_error(CSIC_EINVAL_CHROMA_B, "chroma_b must be equal to chroma_a (%d) or 0. Got %d",
+                         p->chroma_a, p->chroma_b);
+    // ColorQuantizer.scala:12-15
+    const int32_t bits[3] = {p->y_bits, p->cb_bits, p->cr_bits};
+    static const char *const nm[3] = {"Y", "Cb", "Cr"};
+    for (int k = 0; k < 3; ++k)
+        if (bits[k] < 1 || bits[k] > 8)
+            return set_error(CSIC_EINVAL_BITS, "%s target bits must be between 1 and 8. Got %d", nm[k], bits[k]);
+    // ImageCompressorTop.scala:27-31
+    int seen[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+        if (p->op[k] < CSIC_OP_SPATIAL || p->op[k] > CSIC_OP_CHROMA)
+            return set_error(CSIC_EINVAL_OP_PERMUTATION, "op%d must be a valid reorderable operation. Got %d",
+                             k + 1, p->op[k]);
+        if (seen[p->op[k]]++)
+            return set_error(CSIC_EINVAL_OP_PERMUTATION,
+                             "op1, op2, and op3 must be distinct and form a permutation. Got %d,%d,%d",
+                             p->op[0], p->op[1], p->op[2]);
+    }
+    if (p->rounding != CSIC_ROUND_FLOOR_HW && p->rounding != CSIC_ROUND_TRUNC_SW)
+        return set_error(CSIC_EINVAL_ROUNDING, "rounding must be FLOOR_HW(0) or TRUNC_SW(1). Got %d", p->rounding);
+    if (p->sampling != CSIC_SAMPLING_HOLD_DECIMATE)
+        return set_error(CSIC_EINVAL_SAMPLING, "only HOLD_DECIMATE(0) sampling exists. Got %d", p->sampling);
+    if (p->in_format != CSIC_FMT_ARGB8888)
+        return set_error(CSIC_EINVAL_FORMAT, "in_format must be ARGB8888(0). Got %d", p->in_format);
+    if (p->out_format != CSIC_FMT_ARGB8888 && p->out_format != CSIC_FMT_YCBCR888X)
+        return set_error(CSIC_EINVAL_FORMAT, "out_format must be ARGB8888(0) or YCBCR888X(1). Got %d", p->out_format);
+    // ImageProcessor.scala:25 -- a rule of ImageProcessorParams only; the raw RTL accepts any size
+    if (p->strict_divisible && (p->width % p->factor != 0 || p->height % p->factor != 0))
+        return set_error(CSIC_EINVAL_NOT_DIVISIBLE,
+                         "Image dimensions must be divisible by spatial downsampling factor. Got %dx%d, factor %d",
+                         p->width, p->height, p->factor);
+    return CSIC_OK;
+}
+
+int derive_geometry(const csic_params *p, Geometry *g)
+{
+    int st = validate_impl(p);
+    if (st != CSIC_OK) return st;
+    g->W = p->width; g->H = p->height; g->f = p->factor;
+    g->Wo = (p->width + p->factor - 1) / p->factor;
+    g->Ho = (p->height + p->factor - 1) / p->factor;
+    g->h = 4 / p->chroma_a;                       // ChromaSubsampler.scala:26
+    g->v = (p->chroma_b == 0) ? 2 : 1;            // ChromaSubsampler.scala:27
+    int is = 0, ic = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (p->op[k] == CSIC_OP_SPATIAL) is = k;
+        if (p->op[k] == CSIC_OP_CHROMA) ic = k;
+    }
+    // With f == 1 the decimator is the identity and the two order classes coincide.
+    g->s_first = (is < ic && p->factor > 1) ? 1 : 0;
+    g->last_sample_col = ((p->width - 1) / g->h) * g->h;
+    g->mask_y  = (0xFFu << (8 - p->y_bits))  & 0xFFu;   // ColorQuantizer.scala:29-31,42-44
+    g->mask_cb = (0xFFu << (8 - p->cb_bits)) & 0xFFu;
+    g->mask_cr = (0xFFu << (8 - p->cr_bits)) & 0xFFu;
+    return CSIC_OK;
+}
+
+} // namespace csic
+
+using namespace csic;
+
+extern "C" {
+
+int csic_abi_version(void) { return CSIC_ABI_VERSION; }
+
+int csic_params_default(csic_params *p, int32_t width, int32_t height)
+{
+    if (!p) return set_error(CSIC_EINVAL_NULL, "params is NULL");
+    std::memset(p, 0, sizeof *p);
+    p->width = width; p->height = height;
+    p->chroma_a = 4; p->chroma_b = 4;             // ImageProcessorModel.scala:38-39
+    p->y_bits = p->cb_bits = p->cr_bits = 8;
+    p->factor = 1;
+    p->op[0] = CSIC_OP_CHROMA; p->op[1] = CSIC_OP_SPATIAL; p->op[2] = CSIC_OP_QUANT;
+    p->rounding = CSIC_ROUND_FLOOR_HW;
+    p->sampling = CSIC_SAMPLING_HOLD_DECIMATE;
+    p->in_format = p->out_format = CSIC_FMT_ARGB8888;
+    p->strict_divisible = 0;
+    clear_error();
+    return CSIC_OK;
+}
+
+int csic_validate(const csic_params *p)
+{
+    int st = validate_impl(p);
+    if (st == CSIC_OK) clear_error();
+    return st;
+}
+
+int csic_out_dims(const csic_params *p, int32_t *out_width, int32_t *out_height)
+{
+    if (!out_width || !out_height) return set_error(CSIC_EINVAL_NULL, "output pointer is NULL");
+    Geometry g;
+    int st = derive_geometry(p, &g);
+    if (st != CSIC_OK) return st;
+    *out_width = g.Wo; *out_height = g.Ho;
+    clear_error();
+    return CSIC_OK;
+}
+
+int csic_algorithmic_bytes(const csic_params *p, int64_t *bytes)
+{
+    if (!bytes) return set_error(CSIC_EINVAL_NULL, "bytes is NULL");
+    Geometry g;
+    int st = derive_geometry(p, &g);
+    if (st != CSIC_OK) return st;
+    // every byte of each input row that holds a surviving pixel + the output
+    *bytes = 4ll * g.W * g.Ho + 4ll * g.Wo * g.Ho;
+    clear_error();
+    return CSIC_OK;
+}
+
+int csic_stripe_rows(const csic_params *p, int32_t nranks, int32_t rank,
+                     int32_t *row0, int32_t *nrows, int32_t *out_row0, int32_t *out_nrows)
+{
+    if (!row0 || !nrows || !out_row0 || !out_nrows) return set_error(CSIC_EINVAL_NULL, "output pointer is NULL");
+    Geometry g;
+    int st = derive_geometry(p, &g);
+    if (st != CSIC_OK) return st;
+    if (nranks <= 0 || rank < 0 || rank >= nranks)
+        return set_error(CSIC_EINVAL_STRIPE, "bad rank %d of %d", rank, nranks);
+    int64_t L;
+    if (!g.s_first) {
+        // chroma indices are image coordinates: a stripe that starts on a row that is both a
+        // vertical chroma sample row and a decimation row depends on nothing above it.
+        L = (g.v > g.f) ? g.v : g.f;               // lcm of two powers of two
+    } else {
+        // chroma runs on the decimated stream with column counter modulo the FULL width W
+        // (ImageCompressorTop.scala:52-58): one chroma row = W decimated pixels = f decimated rows
+        // = f*f input rows, and only when f divides W.
+        if (g.W % g.f != 0)
+            return set_error(CSIC_EINVAL_STRIPE,
+                             "spatial-before-chroma with width %% factor != 0 cannot be row-striped independently");
+        L = (int64_t)g.v * g.f * g.f;
+    }
+    const int64_t blocks = (g.H + L - 1) / L;
+    const int64_t b0 = blocks * rank / nranks, b1 = blocks * (rank + 1) / nranks;
+    int64_t r0 = b0 * L, r1 = b1 * L;
+    if (r0 > g.H) r0 = g.H;
+    if (r1 > g.H) r1 = g.H;
+    *row0 = (int32_t)r0; *nrows = (int32_t)(r1 - r0);
+    *out_row0 = (int32_t)(r0 / g.f);                         // r0 is a multiple of f
+    *out_nrows = (int32_t)(((r1 - r0) + g.f - 1) / g.f);
+    clear_error();
+    return CSIC_OK;
+}
+
+const char *csic_strerror(int status)
+{
+    switch (status) {
+    case CSIC_OK: return "ok";
+    case CSIC_EINVAL_NULL: return "null argument";
+    case CSIC_EINVAL_DIMS: return "invalid image dimensions";
+    case CSIC_EINVAL_FACTOR: return "invalid spatial factor";
+    case CSIC_EINVAL_CHROMA_A: return "invalid chroma parameter a";
+    case CSIC_EINVAL_CHROMA_B: return "invalid chroma parameter b";
+    case CSIC_EINVAL_BITS: return "invalid quantiser bit depth";
+    case CSIC_EINVAL_OP_PERMUTATION: return "operations are not a permutation";
+    case CSIC_EINVAL_ROUNDING: return "invalid rounding mode";
+    case CSIC_EINVAL_FORMAT: return "invalid pixel format";
+    case CSIC_EINVAL_NOT_DIVISIBLE: return "dimensions not divisible by factor";
+    case CSIC_EINVAL_SAMPLING: return "invalid sampling mode";
+    case CSIC_EINVAL_STRIPE: return "invalid row-stripe request";
+    case CSIC_EINVAL_SIZE: return "buffer size mismatch";
+    case CSIC_ENODEVICE: return "no HIP device";
+    case CSIC_EHIP: return "HIP runtime error";
+    case CSIC_ENOMEM: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+const char *csic_last_error(void) { return g_last_error; }
+
+} // extern "C"

@@ -1,0 +1,604 @@
+// csic_kernels.hip -- the fused pixel pipeline for gfx950 (MI355X) and the device half of the C ABI.
+//
+// One launch turns packed ARGB input pixels into packed reconstructed ARGB (or YCbCr) output pixels:
+//   forward RGB->YCbCr  (RGB2YCbCr.scala:33-65 floor form / :95-121 trunc form)
+//   chroma sample-and-hold (ChromaSubsampler.scala:47-65), closed form of SURVEY.md App. A.3
+//   top-left decimation  (SpatialDownsampler.scala:33-55)
+//   LSB-truncating quantiser (ColorQuantizer.scala:29-31,42-44)
+//   inverse YCbCr->RGB   (YCbCr2RGB.scala:17-26; applied per output pixel by the reference's
+//                         harness, ImageCompressorTopApp.scala:118)
+// Every output pixel is a pure function of at most two input pixels (the one that supplies Y and the
+// one whose chroma is held), so the stream is embarrassingly parallel; the kernels are HBM-bound
+// integer/byte work -- no MFMA, no LDS staging (there is no reuse to stage).
+//
+// Kernel families (all written for wave64, 256-thread blocks laid out bx * by):
+//   k_f1x4   : factor 1, width % 4 == 0.  One lane = 4 consecutive pixels = one 16-byte load and one
+//              16-byte store; held chroma is reused inside the lane (h in {2,4} divides 4), the
+//              4:2:0 odd-row quirk costs one extra (row-uniform) 4-byte load.
+//   k_dec    : factor 2/4/8, chroma before spatial.  Only rows r % f == 0 are touched.  One lane = K
+//              output pixels spaced by the block width, so that every load and store instruction is
+//              lane-contiguous in the OUTPUT (loads stride f*4 bytes across lanes, stores are dense).
+//   k_dec2v  : factor 2 variants with 16-byte loads (A/B candidates for the headline config).
+//   k_generic: one lane = one output pixel, run-time parameters; covers spatial-before-chroma
+//              (chroma counters run on the decimated stream modulo the FULL width,
+//              ImageCompressorTop.scala:52-58) and widths that are not a multiple of 4.
+//
+// Citations are relative to /root/reference/.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "csic_internal.h"
+
+namespace csic {
+
+// ------------------------------------------------------------------------------------------------
+// kernel arguments (kernarg segment -> SGPRs)
+// ------------------------------------------------------------------------------------------------
+struct KArgs {
+    const uint32_t *in;
+    uint32_t *out;
+    int32_t W, H, Wo, Ho;
+    int32_t last_sample_col;
+    uint32_t my, mcb, mcr;
+    int32_t f, hmask, vmask, s_first;   // generic kernel only (hmask = h-1, vmask = v-1)
+    int64_t in_frame_px, out_frame_px;  // batch strides (grid z = frame)
+};
+
+enum { R_FLOOR = CSIC_ROUND_FLOOR_HW, R_TRUNC = CSIC_ROUND_TRUNC_SW };
+enum { F_ARGB = CSIC_FMT_ARGB8888, F_YCC = CSIC_FMT_YCBCR888X };
+
+// ------------------------------------------------------------------------------------------------
+// per-pixel arithmetic
+// ------------------------------------------------------------------------------------------------
+// Pixel bytes (little endian uint32): b0 = B, b1 = G, b2 = R, b3 = A.
+
+// Y = (77R + 150G + 29B + 128) >> 8.  The sum is non-negative, so floor == trunc, and
+// 77 + 150 + 29 = 256 bounds it by 255: no clamp can fire.  One v_dot4_u32_u8 + one shift.
+__device__ __forceinline__ uint32_t fwd_y(uint32_t px)
+{
+    return __builtin_amdgcn_udot4(px, 0x004D961Du /* A:0 R:77 G:150 B:29 */, 128u, false) >> 8;
+}
+
+// Cb/Cr.  Both coefficient rows sum to zero, so biasing every byte by -128 (px ^ 0x80808080 read as
+// i8) does not change the dot product; the +128 coefficient does not fit i8, so the row is negated:
+//   -cbI = 43R' + 85G' - 128B'      -crI = -128R' + 107G' + 21B'
+// FLOOR: ((cbI + 128) >> 8) + 128 == (cbI + 32896) >> 8 (argument always positive); the only clamp
+// that can fire is 256 -> 255.  TRUNC: Scala's '/' rounds toward zero.
+template <int ROUND>
+__device__ __forceinline__ void fwd_c(uint32_t px, uint32_t &cb, uint32_t &cr)
+{
+    const int sx = (int)(px ^ 0x80808080u);
+    const int ncb = __builtin_amdgcn_sdot4(sx, (int)0x002B5580 /* A:0 R:43  G:85  B:-128 */, 0, false);
+    const int ncr = __builtin_amdgcn_sdot4(sx, (int)0x00806B15 /* A:0 R:-128 G:107 B:21  */, 0, false);
+    if (ROUND == R_FLOOR) {
+        cb = (uint32_t)min((32896 - ncb) >> 8, 255);
+        cr = (uint32_t)min((32896 - ncr) >> 8, 255);
+    } else {
+        int tb = 128 - ncb, tr = 128 - ncr;             // cbI + 128, crI + 128
+        tb += (tb >> 31) & 255;                         // trunc toward zero == floor after +255 if negative
+        tr += (tr >> 31) & 255;
+        cb = (uint32_t)min((tb >> 8) + 128, 255);
+        cr = (uint32_t)min((tr >> 8) + 128, 255);
+    }
+}
+
+// Chroma-dependent part of the inverse transform, shared by all pixels that hold the same chroma.
+//   R = clamp((298Y + 409(Cr-128) + 128) >> 8)                 = clamp((298Y + KR) >> 8)
+//   G = clamp((298Y - 100(Cb-128) - 208(Cr-128) + 128) >> 8)   = clamp((298Y + KG) >> 8)
+//   B = clamp((298Y + 516(Cb-128) + 128) >> 8)                 = clamp((298Y + KB) >> 8)
+struct ChromaTerm {
+    int kr, kg, kb;      // ARGB output
+    uint32_t ycc_hi;     // YCC output: Cb << 8 | Cr << 16
+};
+
+template <int ROUND, int FMT>
+__device__ __forceinline__ ChromaTerm chroma_term(uint32_t cpx, uint32_t mcb, uint32_t mcr)
+{
+    uint32_t cb, cr;
+    fwd_c<ROUND>(cpx, cb, cr);
+    cb &= mcb;                                          // quantiser, ColorQuantizer.scala:43-44
+    cr &= mcr;
+    ChromaTerm t;
+    if (FMT == F_ARGB) {
+        t.kr = __mul24((int)cr, 409) - 52224;
+        t.kb = __mul24((int)cb, 516) - 65920;
+        t.kg = 39552 - __mul24((int)cb, 100) - __mul24((int)cr, 208);
+        t.ycc_hi = 0;
+    } else {
+        t.kr = t.kg = t.kb = 0;
+        t.ycc_hi = (cb << 8) | (cr << 16);
+    }
+    return t;
+}
+
+__device__ __forceinline__ int clamp_u8(int v) { return min(max(v, 0), 255); }   // -> v_med3_i32
+
+template <int FMT>
+__device__ __forceinline__ uint32_t finish(uint32_t ypx, uint32_t my, const ChromaTerm &t)
+{
+    const uint32_t y = fwd_y(ypx) & my;                 // quantiser, ColorQuantizer.scala:42
+    if (FMT == F_ARGB) {
+        const int yy = __mul24((int)y, 298);
+        const int r = clamp_u8((yy + t.kr) >> 8);
+        const int g = clamp_u8((yy + t.kg) >> 8);
+        const int b = clamp_u8((yy + t.kb) >> 8);
+        return 0xFF000000u | ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;
+    } else {
+        return y | t.ycc_hi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_f1x4: factor 1, W % 4 == 0, 4 pixels per lane
+// ------------------------------------------------------------------------------------------------
+template <int ROUND, int FMT, int HH, int VV>
+__global__ void __launch_bounds__(256) k_f1x4(KArgs a)
+{
+    const int W4 = a.W >> 2;
+    const int x4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x4 >= W4) return;
+    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
+    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const int row_step = gridDim.y * blockDim.y;
+    for (int row = blockIdx.y * blockDim.y + threadIdx.y; row < a.H; row += row_step) {
+        const int64_t base = (int64_t)row * a.W + 4 * x4;
+        const uint4 p = *reinterpret_cast<const uint4 *>(in + base);
+        const uint32_t px[4] = {p.x, p.y, p.z, p.w};
+        uint32_t o[4];
+        if (VV == 2 && (row & 1)) {
+            // 4:x:0 odd row: no pixel is a sample point, the whole row replays the chroma latched at
+            // the last sample of the previous row (ChromaSubsampler.scala:52-65)
+            const uint32_t cpx = in[(int64_t)(row - 1) * a.W + a.last_sample_col];
+            const ChromaTerm t = chroma_term<ROUND, FMT>(cpx, a.mcb, a.mcr);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = finish<FMT>(px[i], a.my, t);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; g += HH) {
+                const ChromaTerm t = chroma_term<ROUND, FMT>(px[g], a.mcb, a.mcr);
+#pragma unroll
+                for (int i = g; i < g + HH; ++i) o[i] = finish<FMT>(px[i], a.my, t);
+            }
+        }
+        *reinterpret_cast<uint4 *>(out + base) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_dec: factor F in {2,4,8}, chroma before spatial.  K output pixels per lane.
+// With h <= F every surviving pixel is its own chroma sample; the one
+// exception is 4:1:1 with F = 2 (HGTF): chroma comes from column (c & ~3).
+// ------------------------------------------------------------------------------------------------
+template <int ROUND, int FMT, int F, bool HGTF, int K>
+__global__ void __launch_bounds__(256) k_dec(KArgs a)
+{
+    const int bx = blockDim.x;
+    const int co0 = blockIdx.x * (bx * K) + threadIdx.x;
+    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
+    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const int row_step = gridDim.y * blockDim.y;
+    for (int ro = blockIdx.y * blockDim.y + threadIdx.y; ro < a.Ho; ro += row_step) {
+        const uint32_t *rowp = in + (int64_t)(ro * F) * a.W;
+        uint32_t *orow = out + (int64_t)ro * a.Wo;
+        uint32_t px[K], cpx[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int co = co0 + k * bx;
+            if (co < a.Wo) {
+                px[k] = rowp[co * F];
+                cpx[k] = HGTF ? rowp[(co * F) & ~3] : px[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int co = co0 + k * bx;
+            if (co < a.Wo) {
+                const ChromaTerm t = chroma_term<ROUND, FMT>(cpx[k], a.mcb, a.mcr);
+                orow[co] = finish<FMT>(px[k], a.my, t);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_dec2v: factor 2, chroma before spatial, h <= 2, W % 8 == 0 -- 16-byte loads.
+//   VAR 1: one lane = 4 input pixels (one dwordx4 load)  -> 2 output pixels (one dwordx2 store),
+//          loads and stores both dense across lanes.
+//   VAR 2: one lane = 8 input pixels (two dwordx4 loads of its own 32 contiguous bytes)
+//          -> 4 output pixels (one dwordx4 store); load instructions are 50 % dense, stores dense.
+// ------------------------------------------------------------------------------------------------
+template <int ROUND, int FMT, int VAR>
+__global__ void __launch_bounds__(256) k_dec2v(KArgs a)
+{
+    constexpr int OPL = (VAR == 1) ? 2 : 4;             // output pixels per lane
+    const int nx = a.Wo / OPL;                          // lanes per row (W % 8 == 0 -> exact)
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nx) return;
+    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
+    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const int row_step = gridDim.y * blockDim.y;
+    for (int ro = blockIdx.y * blockDim.y + threadIdx.y; ro < a.Ho; ro += row_step) {
+        const uint32_t *rowp = in + (int64_t)(ro * 2) * a.W + (int64_t)x * (OPL * 2);
+        uint32_t *op = out + (int64_t)ro * a.Wo + (int64_t)x * OPL;
+        if (VAR == 1) {
+            const uint4 p = *reinterpret_cast<const uint4 *>(rowp);
+            const ChromaTerm t0 = chroma_term<ROUND, FMT>(p.x, a.mcb, a.mcr);
+            const ChromaTerm t1 = chroma_term<ROUND, FMT>(p.z, a.mcb, a.mcr);
+            *reinterpret_cast<uint2 *>(op) = make_uint2(finish<FMT>(p.x, a.my, t0), finish<FMT>(p.z, a.my, t1));
+        } else {
+            const uint4 p = *reinterpret_cast<const uint4 *>(rowp);
+            const uint4 q = *reinterpret_cast<const uint4 *>(rowp + 4);
+            const ChromaTerm t0 = chroma_term<ROUND, FMT>(p.x, a.mcb, a.mcr);
+            const ChromaTerm t1 = chroma_term<ROUND, FMT>(p.z, a.mcb, a.mcr);
+            const ChromaTerm t2 = chroma_term<ROUND, FMT>(q.x, a.mcb, a.mcr);
+            const ChromaTerm t3 = chroma_term<ROUND, FMT>(q.z, a.mcb, a.mcr);
+            *reinterpret_cast<uint4 *>(op) = make_uint4(finish<FMT>(p.x, a.my, t0), finish<FMT>(p.z, a.my, t1),
+                                                        finish<FMT>(q.x, a.my, t2), finish<FMT>(q.z, a.my, t3));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_generic: any parameters, one output pixel per lane (SURVEY.md App. A.3 / A.4 verbatim)
+// ------------------------------------------------------------------------------------------------
+template <int ROUND, int FMT>
+__global__ void __launch_bounds__(256) k_generic(KArgs a)
+{
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= a.Wo) return;
+    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
+    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const int row_step = gridDim.y * blockDim.y;
+    for (int ro = blockIdx.y * blockDim.y + threadIdx.y; ro < a.Ho; ro += row_step) {
+        const int64_t y_idx = (int64_t)(ro * a.f) * a.W + co * a.f;
+        int64_t c_idx;
+        if (!a.s_first) {
+            const int r = ro * a.f, c = co * a.f;       // chroma counters == image coordinates
+            c_idx = ((r & a.vmask) == 0) ? (int64_t)r * a.W + (c & ~a.hmask)
+                                         : (int64_t)(r - 1) * a.W + a.last_sample_col;
+        } else {
+            // chroma sits behind the decimator but was built with the full width
+            // (ImageCompressorTop.scala:52-58): its column counter wraps every W decimated pixels.
+            const int j = ro * a.Wo + co;               // < 2^31 (validated)
+            const int r = j / a.W, c = j - r * a.W;
+            const int src = ((r & a.vmask) == 0) ? (j - (c & a.hmask)) : ((r - 1) * a.W + a.last_sample_col);
+            const int sro = src / a.Wo, sco = src - sro * a.Wo;
+            c_idx = (int64_t)(sro * a.f) * a.W + sco * a.f;
+        }
+        const ChromaTerm t = chroma_term<ROUND, FMT>(in[c_idx], a.mcb, a.mcr);
+        out[(int64_t)ro * a.Wo + co] = finish<FMT>(in[y_idx], a.my, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// utilities: synthetic frames and checksum
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+
+__global__ void __launch_bounds__(256) k_synth(uint32_t *dst, int64_t npix, int64_t first_index, uint32_t salt)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride)
+        dst[i] = 0xFF000000u | (fmix32((uint32_t)(first_index + i) + salt) & 0x00FFFFFFu);
+}
+
+__global__ void __launch_bounds__(256) k_checksum(const uint32_t *src, int64_t npix, unsigned long long *sum)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride)
+        acc += fmix32(src[i] + 0x9E3779B9u * (uint32_t)i);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------------
+using KernelFn = void (*)(KArgs);
+
+enum Family { FAM_F1X4, FAM_DEC, FAM_DEC2V1, FAM_DEC2V2, FAM_GENERIC };
+
+} // namespace csic
+
+struct csic_plan {
+    csic_params p;
+    csic::Geometry g;
+    int device;
+    int variant;
+    int force_generic;
+    // selection (recomputed by select())
+    csic::Family fam;
+    csic::KernelFn fn;
+    int units_per_row;   // lanes needed along x
+    int k_per_lane;      // x units consumed per lane (k_dec only)
+    char name[96];
+    // host path staging
+    void *d_in, *d_out;
+    unsigned long long *d_sum;
+};
+
+namespace csic {
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return set_error(CSIC_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));          \
+    } while (0)
+
+template <int ROUND, int FMT>
+static KernelFn pick_f1x4(int h, int v)
+{
+    if (v == 1) {
+        if (h == 1) return k_f1x4<ROUND, FMT, 1, 1>;
+        if (h == 2) return k_f1x4<ROUND, FMT, 2, 1>;
+        return k_f1x4<ROUND, FMT, 4, 1>;
+    }
+    if (h == 1) return k_f1x4<ROUND, FMT, 1, 2>;
+    if (h == 2) return k_f1x4<ROUND, FMT, 2, 2>;
+    return k_f1x4<ROUND, FMT, 4, 2>;
+}
+
+constexpr int DEC_K = 4;
+
+template <int ROUND, int FMT>
+static KernelFn pick_dec(int f, bool hgtf)
+{
+    if (f == 2) return hgtf ? (KernelFn)k_dec<ROUND, FMT, 2, true, DEC_K> : (KernelFn)k_dec<ROUND, FMT, 2, false, DEC_K>;
+    if (f == 4) return k_dec<ROUND, FMT, 4, false, DEC_K>;
+    return k_dec<ROUND, FMT, 8, false, DEC_K>;
+}
+
+template <int ROUND, int FMT>
+static void select_rf(csic_plan *pl)
+{
+    const Geometry &g = pl->g;
+    const char *rn = ROUND == R_FLOOR ? "floor" : "trunc";
+    const char *fn = FMT == F_ARGB ? "argb" : "ycc";
+    if (!pl->force_generic && g.f == 1 && g.W % 4 == 0) {
+        pl->fam = FAM_F1X4;
+        pl->fn = pick_f1x4<ROUND, FMT>(g.h, g.v);
+        pl->units_per_row = g.W / 4;
+        pl->k_per_lane = 1;
+        snprintf(pl->name, sizeof pl->name, "k_f1x4<%s,%s,h%d,v%d>", rn, fn, g.h, g.v);
+    } else if (!pl->force_generic && g.f > 1 && !g.s_first) {
+        const bool hgtf = g.h > g.f;
+        if (g.f == 2 && !hgtf && g.W % 8 == 0 && (pl->variant == 1 || pl->variant == 2)) {
+            pl->fam = pl->variant == 1 ? FAM_DEC2V1 : FAM_DEC2V2;
+            pl->fn = pl->variant == 1 ? (KernelFn)k_dec2v<ROUND, FMT, 1> : (KernelFn)k_dec2v<ROUND, FMT, 2>;
+            pl->units_per_row = g.Wo / (pl->variant == 1 ? 2 : 4);
+            pl->k_per_lane = 1;
+            snprintf(pl->name, sizeof pl->name, "k_dec2v<%s,%s,var%d>", rn, fn, pl->variant);
+        } else {
+            pl->fam = FAM_DEC;
+            pl->fn = pick_dec<ROUND, FMT>(g.f, hgtf);
+            pl->units_per_row = g.Wo;
+            pl->k_per_lane = DEC_K;
+            snprintf(pl->name, sizeof pl->name, "k_dec<%s,%s,f%d,%s,K%d>", rn, fn, g.f, hgtf ? "h>f" : "h<=f", DEC_K);
+        }
+    } else {
+        pl->fam = FAM_GENERIC;
+        pl->fn = k_generic<ROUND, FMT>;
+        pl->units_per_row = g.Wo;
+        pl->k_per_lane = 1;
+        snprintf(pl->name, sizeof pl->name, "k_generic<%s,%s>", rn, fn);
+    }
+}
+
+static void select(csic_plan *pl)
+{
+    const int r = pl->p.rounding, f = pl->p.out_format;
+    if (r == R_FLOOR && f == F_ARGB) select_rf<R_FLOOR, F_ARGB>(pl);
+    else if (r == R_FLOOR) select_rf<R_FLOOR, F_YCC>(pl);
+    else if (f == F_ARGB) select_rf<R_TRUNC, F_ARGB>(pl);
+    else select_rf<R_TRUNC, F_YCC>(pl);
+}
+
+static int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+static int ensure_device(const csic_plan *pl)
+{
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != pl->device) HIP_TRY(hipSetDevice(pl->device));
+    return CSIC_OK;
+}
+
+static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream)
+{
+    if (!pl) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
+    if (!d_in || !d_out) return set_error(CSIC_EINVAL_NULL, "device buffer is NULL");
+    if (nframes <= 0) return set_error(CSIC_EINVAL_SIZE, "nframes must be positive. Got %d", nframes);
+    int st = ensure_device(pl);
+    if (st != CSIC_OK) return st;
+    const Geometry &g = pl->g;
+
+    Family fam = pl->fam;
+    KernelFn fn = pl->fn;
+    int units = pl->units_per_row, kpl = pl->k_per_lane;
+    // The vector kernels need 16-byte aligned frame bases; otherwise take the generic kernel.
+    const bool vec = (fam == FAM_F1X4 || fam == FAM_DEC2V1 || fam == FAM_DEC2V2);
+    if (vec && ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15u)) {
+        csic_plan tmp = *pl;
+        tmp.force_generic = 1;
+        select(&tmp);
+        fam = tmp.fam; fn = tmp.fn; units = tmp.units_per_row; kpl = tmp.k_per_lane;
+    }
+
+    KArgs a;
+    a.in = static_cast<const uint32_t *>(d_in);
+    a.out = static_cast<uint32_t *>(d_out);
+    a.W = g.W; a.H = g.H; a.Wo = g.Wo; a.Ho = g.Ho;
+    a.last_sample_col = g.last_sample_col;
+    a.my = g.mask_y; a.mcb = g.mask_cb; a.mcr = g.mask_cr;
+    a.f = g.f; a.hmask = g.h - 1; a.vmask = g.v - 1; a.s_first = g.s_first;
+    a.in_frame_px = (int64_t)g.W * g.H;
+    a.out_frame_px = (int64_t)g.Wo * g.Ho;
+
+    const int rows = (fam == FAM_F1X4) ? g.H : g.Ho;
+    const int lanes_x = (units + kpl - 1) / kpl;
+    int bx = pow2_ceil(lanes_x);
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    const int by = 256 / bx;
+    dim3 block(bx, by, 1);
+    unsigned gx = (unsigned)((lanes_x + bx - 1) / bx);
+    unsigned gy = (unsigned)((rows + by - 1) / by);
+    if (gy > 65535u) gy = 65535u;                     // kernels stride over rows
+    for (int f0 = 0; f0 < nframes; f0 += 65535) {     // grid z limit
+        const int nz = (nframes - f0 < 65535) ? nframes - f0 : 65535;
+        KArgs b = a;
+        b.in += (int64_t)f0 * a.in_frame_px;
+        b.out += (int64_t)f0 * a.out_frame_px;
+        hipLaunchKernelGGL(fn, dim3(gx, gy, (unsigned)nz), block, 0, stream, b);
+        HIP_TRY(hipGetLastError());
+    }
+    clear_error();
+    return CSIC_OK;
+}
+
+} // namespace csic
+
+using namespace csic;
+
+extern "C" {
+
+int csic_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice || (e == hipSuccess && n == 0))
+        return set_error(CSIC_ENODEVICE, "no HIP device visible (libcsic_hip has no CPU fallback)");
+    if (e != hipSuccess) return set_error(CSIC_EHIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    clear_error();
+    return n;
+}
+
+int csic_plan_create(const csic_params *p, int device, csic_plan **out)
+{
+    if (!out) return set_error(CSIC_EINVAL_NULL, "out is NULL");
+    *out = nullptr;
+    Geometry g;
+    int st = derive_geometry(p, &g);
+    if (st != CSIC_OK) return st;
+    const int n = csic_device_count();
+    if (n < 0) return n;
+    if (device < 0 || device >= n)
+        return set_error(CSIC_ENODEVICE, "device %d out of range (have %d; there is no CPU backend)", device, n);
+    csic_plan *pl = new (std::nothrow) csic_plan();
+    if (!pl) return set_error(CSIC_ENOMEM, "out of host memory");
+    std::memset(pl, 0, sizeof *pl);
+    pl->p = *p; pl->g = g; pl->device = device;
+    select(pl);
+    *out = pl;
+    clear_error();
+    return CSIC_OK;
+}
+
+int csic_plan_destroy(csic_plan *plan)
+{
+    if (!plan) return CSIC_OK;
+    if (plan->d_in || plan->d_out || plan->d_sum) {
+        if (ensure_device(plan) == CSIC_OK) {
+            if (plan->d_in) (void)hipFree(plan->d_in);
+            if (plan->d_out) (void)hipFree(plan->d_out);
+            if (plan->d_sum) (void)hipFree(plan->d_sum);
+        }
+    }
+    delete plan;
+    return CSIC_OK;
+}
+
+const char *csic_plan_kernel_name(const csic_plan *plan) { return plan ? plan->name : ""; }
+
+int csic_plan_tune(csic_plan *plan, int32_t knob, int32_t value)
+{
+    if (!plan) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
+    if (knob == CSIC_TUNE_VARIANT) plan->variant = value;
+    else if (knob == CSIC_TUNE_FORCE_GENERIC) plan->force_generic = value ? 1 : 0;
+    else return set_error(CSIC_EINVAL_SIZE, "unknown tuning knob %d", knob);
+    select(plan);
+    clear_error();
+    return CSIC_OK;
+}
+
+int csic_process_device(csic_plan *plan, const void *d_in, void *d_out, void *hip_stream)
+{
+    return launch(plan, d_in, d_out, 1, static_cast<hipStream_t>(hip_stream));
+}
+
+int csic_process_batch_device(csic_plan *plan, const void *d_in, void *d_out, int32_t nframes, void *hip_stream)
+{
+    return launch(plan, d_in, d_out, nframes, static_cast<hipStream_t>(hip_stream));
+}
+
+int csic_process_host(csic_plan *plan, const uint32_t *in, size_t in_px, uint32_t *out, size_t out_px)
+{
+    if (!plan) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
+    if (!in || !out) return set_error(CSIC_EINVAL_NULL, "host buffer is NULL");
+    const Geometry &g = plan->g;
+    const size_t need_in = (size_t)g.W * g.H, need_out = (size_t)g.Wo * g.Ho;
+    if (in_px != need_in || out_px != need_out)
+        return set_error(CSIC_EINVAL_SIZE, "expected %zu input and %zu output pixels, got %zu and %zu",
+                         need_in, need_out, in_px, out_px);
+    int st = ensure_device(plan);
+    if (st != CSIC_OK) return st;
+    if (!plan->d_in) HIP_TRY(hipMalloc(&plan->d_in, need_in * 4));
+    if (!plan->d_out) HIP_TRY(hipMalloc(&plan->d_out, need_out * 4));
+    HIP_TRY(hipMemcpyAsync(plan->d_in, in, need_in * 4, hipMemcpyHostToDevice, nullptr));
+    st = launch(plan, plan->d_in, plan->d_out, 1, nullptr);
+    if (st != CSIC_OK) return st;
+    HIP_TRY(hipMemcpyAsync(out, plan->d_out, need_out * 4, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    clear_error();
+    return CSIC_OK;
+}
+
+int csic_synth_frame_device(void *d_dst, int64_t npix, int64_t first_index, uint32_t seed, void *hip_stream)
+{
+    if (!d_dst) return set_error(CSIC_EINVAL_NULL, "d_dst is NULL");
+    if (npix < 0) return set_error(CSIC_EINVAL_SIZE, "npix must be >= 0");
+    if (npix == 0) return CSIC_OK;
+    int64_t blocks = (npix + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       static_cast<uint32_t *>(d_dst), npix, first_index, seed * 0x9E3779B9u);
+    HIP_TRY(hipGetLastError());
+    clear_error();
+    return CSIC_OK;
+}
+
+int csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *hip_stream)
+{
+    if (!d_src || !sum) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    unsigned long long *d_sum = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_sum), sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), s);
+    if (e == hipSuccess && npix > 0) {
+        int64_t blocks = (npix + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_checksum, dim3((unsigned)blocks), dim3(256), 0, s,
+                           static_cast<const uint32_t *>(d_src), npix, d_sum);
+        e = hipGetLastError();
+    }
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_sum, sizeof h, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_sum);
+    if (e != hipSuccess) return set_error(CSIC_EHIP, "checksum failed: %s", hipGetErrorString(e));
+    *sum = h;
+    clear_error();
+    return CSIC_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,185 @@
+/*
+ * csic.h -- C ABI of libcsic_hip.so: the MI355X (gfx950) implementation of the reference's
+ * pixel-stream hot path
+ *
+ *     RGB2YCbCr -> {ChromaSubsampler, SpatialDownsampler, ColorQuantizer in any order} -> YCbCr2RGB
+ *
+ * The reference (Scala/Chisel, /root/reference) has no FFI: its "interface" for this path is the
+ * generator surface -- constructor parameter lists and require()s.  Each entry point below names the
+ * reference interface it stands in for (paths relative to /root/reference/).  INTEGRATION.md shows the
+ * JNI / Panama binding a maintainer of the reference would add on the Scala side.
+ *
+ * Conventions: plain C, no C++ types, no exceptions across the boundary.  Every function returning
+ * `int` returns CSIC_OK (0) or a negative csic_status; a human-readable message for the calling
+ * thread's last failure is available from csic_last_error().  The caller owns every pixel buffer; the
+ * library owns only the opaque plan.  A plan is not thread-safe; distinct plans are independent.
+ * There is NO CPU fallback: compute entry points fail with CSIC_ENODEVICE when no HIP device exists.
+ *
+ * Pixel layout (one uint32 per pixel, little endian):
+ *   CSIC_FMT_ARGB8888 : byte0=B byte1=G byte2=R byte3=A  == Java `int` ARGB, what scrimage /
+ *                       BufferedImage hand out (ImageProcessorModel.scala:47-48).  Input alpha is
+ *                       ignored; output alpha is 255 (ImageCompressorTopApp.scala:139).
+ *   CSIC_FMT_YCBCR888X: byte0=Y byte1=Cb byte2=Cr byte3=0 -- the PixelYCbCrBundle that
+ *                       ImageCompressorTop.io.out carries (ImageCompressorTop.scala:35,
+ *                       PixelBundle.scala:11-15), i.e. the pipeline WITHOUT the host-side inverse.
+ * Frames are row-major, tightly packed (row pitch = width * 4 bytes).
+ */
+#ifndef CSIC_H
+#define CSIC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSIC_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------------
+ * Every CSIC_EINVAL_* corresponds to a require() that throws IllegalArgumentException when the
+ * reference's generator is constructed; a host binding maps them to IllegalArgumentException. */
+typedef enum csic_status {
+    CSIC_OK                     =   0,
+    CSIC_EINVAL_NULL            =  -1, /* null pointer argument                                       */
+    CSIC_EINVAL_DIMS            =  -2, /* ImageProcessor.scala:22-23, ChromaSubsampler.scala:13-14     */
+    CSIC_EINVAL_FACTOR          =  -3, /* ImageProcessor.scala:24, SpatialDownsampler.scala:8          */
+    CSIC_EINVAL_CHROMA_A        =  -4, /* ImageProcessor.scala:27, ChromaSubsampler.scala:17           */
+    CSIC_EINVAL_CHROMA_B        =  -5, /* ImageProcessor.scala:28, ChromaSubsampler.scala:18           */
+    CSIC_EINVAL_BITS            =  -6, /* ColorQuantizer.scala:12-15                                   */
+    CSIC_EINVAL_OP_PERMUTATION  =  -7, /* ImageCompressorTop.scala:27-31                               */
+    CSIC_EINVAL_ROUNDING        =  -8,
+    CSIC_EINVAL_FORMAT          =  -9,
+    CSIC_EINVAL_NOT_DIVISIBLE   = -10, /* ImageProcessor.scala:25 (only when strict_divisible != 0)    */
+    CSIC_EINVAL_SAMPLING        = -11,
+    CSIC_EINVAL_STRIPE          = -12, /* row-stripe request that cannot be made independent           */
+    CSIC_EINVAL_SIZE            = -13, /* buffer size does not match the plan                          */
+    CSIC_ENODEVICE              = -20, /* no HIP device / bad device ordinal                           */
+    CSIC_EHIP                   = -21, /* a HIP runtime call failed (message has the HIP error string) */
+    CSIC_ENOMEM                 = -22
+} csic_status;
+
+/* ---- enumerations -------------------------------------------------------------------------------*/
+/* ProcessingStep ordinals, ImageCompressorTop.scala:7-9 */
+#define CSIC_OP_NOOP      0
+#define CSIC_OP_SPATIAL   1   /* ProcessingStep.SpatialSampling   */
+#define CSIC_OP_QUANT     2   /* ProcessingStep.ColorQuantization */
+#define CSIC_OP_CHROMA    3   /* ProcessingStep.ChromaSubsampling */
+
+/* Forward-transform rounding: both exist in the reference and both are pinned by
+ * committed golden images. */
+#define CSIC_ROUND_FLOOR_HW 0 /* RTL + ReferenceModel: (x+128) >> 8     RGB2YCbCr.scala:50-65       */
+#define CSIC_ROUND_TRUNC_SW 1 /* YCbCrUtils.rgbToYCbCr: (x+128) / 256   RGB2YCbCr.scala:111-118     */
+
+/* Sampling semantics.  Only the reference-exact one exists: chroma sample-and-hold
+ * (ChromaSubsampler.scala:47-65) and top-left decimation (SpatialDownsampler.scala:33-55). */
+#define CSIC_SAMPLING_HOLD_DECIMATE 0
+
+#define CSIC_FMT_ARGB8888  0
+#define CSIC_FMT_YCBCR888X 1  /* out_format only */
+
+/* ---- parameters ---------------------------------------------------------------------------------
+ * Field-for-field the constructor list of
+ *   class ImageCompressorTop(width, height, chroma_param_a_config, chroma_param_b_config,
+ *                            yTargetQuantBitsConfig, cbTargetQuantBitsConfig, crTargetQuantBitsConfig,
+ *                            downFactorConfig, op1Type, op2Type, op3Type)   ImageCompressorTop.scala:11-25
+ * (ImageProcessorParams, ImageProcessor.scala:15-21, is the subset width/height/factor/a/b with
+ * bits = 8,8,8, op = {CHROMA, SPATIAL, QUANT} and strict_divisible = 1.) */
+typedef struct csic_params {
+    int32_t width, height;
+    int32_t chroma_a, chroma_b;          /* J:a:b with J = 4: a in {4,2,1}, b in {a,0}                */
+    int32_t y_bits, cb_bits, cr_bits;    /* 1..8 significant bits kept per channel                    */
+    int32_t factor;                      /* spatial decimation factor 1,2,4,8                         */
+    int32_t op[3];                       /* permutation of CSIC_OP_{SPATIAL,QUANT,CHROMA}             */
+    int32_t rounding;                    /* CSIC_ROUND_*                                              */
+    int32_t sampling;                    /* CSIC_SAMPLING_HOLD_DECIMATE                               */
+    int32_t in_format, out_format;       /* CSIC_FMT_*                                                */
+    int32_t strict_divisible;            /* 1 = enforce ImageProcessorParams' divisibility require()  */
+} csic_params;
+
+typedef struct csic_plan csic_plan;      /* opaque */
+
+/* ---- host-only logic (usable without a GPU) -----------------------------------------------------*/
+int  csic_abi_version(void);
+
+/* Fills *p with 4:4:4, 8/8/8 bits, factor 1, order chroma->spatial->quant (the north-star order),
+ * FLOOR_HW rounding, ARGB in/out, non-strict.  Mirrors ImageProcessorModel.getImageParams
+ * (ImageProcessorModel.scala:33-41), which defaults chroma to 4:4:4. */
+int  csic_params_default(csic_params *p, int32_t width, int32_t height);
+
+/* All the reference's require()s in one call (see csic_status).  Replaces the construction-time checks
+ * of ImageProcessorParams / ChromaSubsampler / SpatialDownsampler / ColorQuantizer / ImageCompressorTop. */
+int  csic_validate(const csic_params *p);
+
+/* Output frame size: ceil(W/f) x ceil(H/f) -- what SpatialDownsampler emits
+ * (SpatialDownsampler.scala:33-55; 5x3,f=2 -> 3x2, SpatialDownsamplerSpec.scala:120-122). */
+int  csic_out_dims(const csic_params *p, int32_t *out_width, int32_t *out_height);
+
+/* Algorithmic HBM bytes of one frame, the roofline numerator of SURVEY.md 8(d):
+ *   A = 4*W*ceil(H/f) + 4*ceil(W/f)*ceil(H/f)
+ * (every input row that holds a surviving pixel, plus the output; rows r % f != 0 are dead). */
+int  csic_algorithmic_bytes(const csic_params *p, int64_t *bytes);
+
+/* Row-stripe partition for `nranks` devices.  Stripe boundaries are aligned to
+ * L = lcm(v, f) input rows (chroma before spatial) or v*f*f rows (spatial before chroma), which makes
+ * every stripe an independent image of height *nrows: no halo, no collective.  Fails with
+ * CSIC_EINVAL_STRIPE when the order class/shape cannot be split independently (spatial-before-chroma
+ * with width % factor != 0).  Empty stripes (nrows == 0) are possible when nranks exceeds the number
+ * of aligned row blocks. */
+int  csic_stripe_rows(const csic_params *p, int32_t nranks, int32_t rank,
+                      int32_t *row0, int32_t *nrows, int32_t *out_row0, int32_t *out_nrows);
+
+const char *csic_strerror(int status);
+const char *csic_last_error(void);       /* thread-local; "" when the last call succeeded */
+
+/* ---- device path --------------------------------------------------------------------------------*/
+int  csic_device_count(void);            /* >= 0, or CSIC_ENODEVICE / CSIC_EHIP */
+
+/* Validates, selects and specialises the fused kernel for `p` on HIP device `device`.  Stands in for
+ * `new ImageCompressorTop(...)` (ImageCompressorTopApp.scala:53-66) / `new ImageProcessor(params)`
+ * (SpatialDownsamplerSpec.scala:180): parameters are generate-time constants there and plan-time
+ * constants here.  There is no CPU backend: device must be >= 0. */
+int  csic_plan_create(const csic_params *p, int device, csic_plan **out);
+int  csic_plan_destroy(csic_plan *plan);
+
+/* Name of the kernel variant the plan dispatches to (static string owned by the plan), for logs,
+ * tests and matching rocprofv3 kernel names. */
+const char *csic_plan_kernel_name(const csic_plan *plan);
+
+/* Tuning knobs for A/B measurements; a knob the selected kernel does not have is ignored.
+ *   CSIC_TUNE_VARIANT : kernel-family specific variant index (0 = default)
+ *   CSIC_TUNE_FORCE_GENERIC : 1 = always use the one-thread-per-pixel generic kernel */
+#define CSIC_TUNE_VARIANT        1
+#define CSIC_TUNE_FORCE_GENERIC  2
+int  csic_plan_tune(csic_plan *plan, int32_t knob, int32_t value);
+
+/* One frame, device-resident: d_in holds width*height input pixels, d_out receives
+ * out_width*out_height pixels.  Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream);
+ * no allocation, no synchronisation, hipGraph-capturable.  Replaces the per-pixel poke/peek loops
+ * around the simulated RTL plus the host inverse transform
+ * (ImageCompressorTopApp.scala:76-124, :118). */
+int  csic_process_device(csic_plan *plan, const void *d_in, void *d_out, void *hip_stream);
+
+/* `nframes` frames laid out back to back (frame k at d_in + k*W*H*4, d_out + k*Wo*Ho*4) in ONE launch
+ * (frame index on the grid's z axis); same stream semantics as csic_process_device. */
+int  csic_process_batch_device(csic_plan *plan, const void *d_in, void *d_out, int32_t nframes,
+                               void *hip_stream);
+
+/* Convenience synchronous host path: H2D + kernel + D2H through plan-owned staging buffers.
+ * in_px must equal width*height and out_px out_width*out_height. */
+int  csic_process_host(csic_plan *plan, const uint32_t *in, size_t in_px, uint32_t *out, size_t out_px);
+
+/* Synthetic frame generator of SURVEY.md 8(d), on the device:
+ *   dst[i] = 0xFF000000 | (fmix32((uint32)(first_index + i) + seed * 0x9E3779B9) & 0xFFFFFF)
+ * Used by bench.py and the full-size property tests so that frames never cross PCIe. */
+int  csic_synth_frame_device(void *d_dst, int64_t npix, int64_t first_index, uint32_t seed,
+                             void *hip_stream);
+
+/* 64-bit order-sensitive checksum of npix pixels in device memory (sum of fmix32-mixed
+ * (pixel, index) pairs), for the full-size parity properties; synchronous. */
+int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSIC_H */

@@ -1,0 +1,253 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libcsic_hip.so), against the CPU
+oracle and the reference's golden PNGs.  Bit-exact (integer/byte work): every comparison is
+np.array_equal.  Run with `-m gpu` on an MI355X."""
+import ctypes as C
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_png_rgb
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(GOLDEN, "manifest.json")) as _fh:
+    _GOLDENS = json.load(_fh)["goldens"]
+
+ORDERS = list(itertools.permutations((1, 2, 3)))
+CSQ = (3, 1, 2)
+
+
+@pytest.fixture(scope="module")
+def csic():
+    import csic_amd
+    assert csic_amd._native.lib().csic_device_count() >= 1
+    return csic_amd
+
+
+def _plan(csic, W, H, a=4, b=4, bits=(8, 8, 8), f=1, op=CSQ, rounding=0, fmt=0):
+    cp = csic.make_c_params(W, H, a, b, *bits, f, op, rounding=rounding, out_format=fmt)
+    return csic.Plan(cp, 0)
+
+
+def _oparams(orc, W, H, a=4, b=4, bits=(8, 8, 8), f=1, op=CSQ, rounding=0, fmt=0):
+    return orc.OracleParams(width=W, height=H, chroma_a=a, chroma_b=b, y_bits=bits[0], cb_bits=bits[1],
+                            cr_bits=bits[2], factor=f, op=op, rounding=rounding, out_format=fmt)
+
+
+# ---- the reference's golden images through the HIP path -----------------------------------------
+@pytest.mark.parametrize("e", [g for g in _GOLDENS if g["rounding"] != "IDENTITY"],
+                         ids=[g["name"] for g in _GOLDENS if g["rounding"] != "IDENTITY"])
+def test_hip_reproduces_golden(csic, oracle, input_images, e):
+    rgb_in = input_images[e["input"]]
+    want = load_png_rgb(os.path.join(GOLDEN, e["file"]))
+    h, w = rgb_in.shape[:2]
+    rounding = 1 if e["rounding"] == "TRUNC_SW" else 0
+    with _plan(csic, w, h, e["chroma_a"], e["chroma_b"], e["bits"], e["factor"], e["op"], rounding) as pl:
+        got = oracle.argb_to_rgb(pl.process_host(oracle.rgb_to_argb(rgb_in)))
+    assert np.array_equal(got, want)
+
+
+# ---- random shapes / parameters, every kernel family ---------------------------------------------
+@pytest.mark.parametrize("seed", range(4))
+def test_random_shapes_vs_oracle(csic, oracle, seed):
+    rng = np.random.default_rng(4242 + seed)
+    seen = set()
+    for _ in range(150):
+        W = int(rng.integers(1, 97))
+        H = int(rng.integers(1, 41))
+        if rng.random() < 0.5:
+            W = (W + 7) // 8 * 8                       # exercise the vector kernels often
+        a, b = [(4, 4), (2, 2), (2, 0), (1, 1), (4, 0), (1, 0)][int(rng.integers(0, 6))]
+        bits = tuple(int(x) for x in rng.integers(1, 9, 3))
+        f = int(rng.choice([1, 2, 4, 8]))
+        op = ORDERS[int(rng.integers(0, 6))]
+        rounding, fmt = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        argb = rng.integers(0, 1 << 32, W * H, dtype=np.uint32)
+        want = oracle.process(_oparams(oracle, W, H, a, b, bits, f, op, rounding, fmt), argb)
+        with _plan(csic, W, H, a, b, bits, f, op, rounding, fmt) as pl:
+            seen.add(pl.kernel_name.split("<")[0])
+            got = pl.process_host(argb)
+            assert np.array_equal(got, want), (pl.kernel_name, W, H, a, b, bits, f, op, rounding, fmt)
+            for variant in (1, 2):                      # 16-byte-load variants of the f=2 kernel
+                pl.tune(csic._native.TUNE_VARIANT, variant)
+                assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
+            pl.tune(csic._native.TUNE_FORCE_GENERIC, 1)
+            assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
+    assert {"k_f1x4", "k_dec", "k_generic"} <= seen
+
+
+@pytest.mark.parametrize("a,b", [(4, 4), (2, 2), (2, 0), (1, 1), (1, 0), (4, 0)])
+@pytest.mark.parametrize("f", [1, 2, 4, 8])
+def test_every_mode_medium_frame(csic, oracle, a, b, f):
+    """1000x250 (wide enough for 256-lane rows; H not a multiple of 8) in both order classes."""
+    W, H = 1000, 250
+    argb = oracle.synth_frame(W * H, 12345)
+    for op, rounding in itertools.product([(3, 1, 2), (1, 3, 2)], (0, 1)):
+        want = oracle.process(_oparams(oracle, W, H, a, b, (3, 3, 2), f, op, rounding), argb, form="closed")
+        with _plan(csic, W, H, a, b, (3, 3, 2), f, op, rounding) as pl:
+            assert np.array_equal(pl.process_host(argb), want), pl.kernel_name
+
+
+# ---- exhaustive colour cube ----------------------------------------------------------------------
+@pytest.mark.parametrize("rounding", [0, 1])
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_exhaustive_cube(csic, oracle, rounding, fmt):
+    """All 2^24 RGB values as one 4096x4096 frame: forward (+inverse) arithmetic is exact everywhere."""
+    cube = np.arange(1 << 24, dtype=np.uint32)
+    want = oracle.process(_oparams(oracle, 4096, 4096, rounding=rounding, fmt=fmt), cube, form="closed")
+    with _plan(csic, 4096, 4096, rounding=rounding, fmt=fmt) as pl:
+        assert np.array_equal(pl.process_host(cube), want)
+
+
+def test_exhaustive_cube_quantised_444_to_411(csic, oracle):
+    cube = np.arange(1 << 24, dtype=np.uint32)
+    for (a, b), bits in [((2, 0), (3, 3, 2)), ((1, 1), (6, 5, 5)), ((2, 2), (1, 1, 1))]:
+        want = oracle.process(_oparams(oracle, 4096, 4096, a, b, bits), cube, form="closed")
+        with _plan(csic, 4096, 4096, a, b, bits) as pl:
+            assert np.array_equal(pl.process_host(cube), want)
+
+
+# ---- BASELINE.json configs at full size -----------------------------------------------------------
+def test_cfg1_16x16_444(csic, oracle, input_images):
+    """cfg 1: in16x16.png, 4:4:4, no quant, sf=1 through getImageParams-style defaults."""
+    argb = oracle.rgb_to_argb(input_images["in16"])
+    for rounding in (0, 1):
+        want = oracle.process(_oparams(oracle, 16, 16, rounding=rounding), argb)
+        top = csic.ImageCompressorTop(16, 16, 4, 4, 8, 8, 8, 1, 3, 1, 2, rounding=rounding)
+        assert np.array_equal(top.process(argb), want)
+        top.close()
+
+
+def test_cfg2_128_422_q8(csic, oracle, input_images):
+    argb = oracle.rgb_to_argb(input_images["in128"])
+    want = oracle.process(_oparams(oracle, 128, 128, 2, 2, (3, 3, 2)), argb)
+    with _plan(csic, 128, 128, 2, 2, (3, 3, 2)) as pl:
+        assert pl.kernel_name.startswith("k_f1x4")
+        assert np.array_equal(pl.process_host(argb), want)
+
+
+def test_cfg3_512_420_q8_sf2(csic, oracle, input_images):
+    argb = oracle.rgb_to_argb(input_images["in512"])
+    want = oracle.process(_oparams(oracle, 512, 512, 2, 0, (3, 3, 2), 2), argb)
+    with _plan(csic, 512, 512, 2, 0, (3, 3, 2), 2) as pl:
+        got = pl.process_host(argb)
+    assert got.shape == (256, 256) and np.array_equal(got, want)
+
+
+def test_cfg4_8k_420_sf2_device_resident(csic, oracle):
+    """cfg 4 (the headline): synthetic 8192x8192, 4:2:0, sf=2, frames generated on the device."""
+    import torch
+    W = H = 8192
+    lib = csic._native.lib()
+    d_in = torch.empty(W * H, dtype=torch.int32, device="cuda:0")
+    stream = C.c_void_p(torch.cuda.current_stream(0).cuda_stream)
+    csic._native.check(lib.csic_synth_frame_device(C.c_void_p(d_in.data_ptr()), W * H, 0, 20250629, stream))
+    host_in = oracle.synth_frame(W * H, 0)
+    assert np.array_equal(d_in.cpu().numpy().view(np.uint32), host_in)        # generator parity
+    want = oracle.process(_oparams(oracle, W, H, 2, 0, (8, 8, 8), 2), host_in, form="closed")
+    with _plan(csic, W, H, 2, 0, (8, 8, 8), 2) as pl:
+        assert pl.algorithmic_bytes == 201326592
+        for variant in (0, 1, 2):
+            pl.tune(csic._native.TUNE_VARIANT, variant)
+            d_out = pl.process_device(d_in)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_out.cpu().numpy().view(np.uint32), want), pl.kernel_name
+        # checksum-of-output property through the ABI's device checksum
+        s = C.c_uint64()
+        csic._native.check(lib.csic_checksum_device(C.c_void_p(d_out.data_ptr()), d_out.numel(), C.byref(s), stream))
+        idx = np.arange(want.size, dtype=np.uint32)
+        h = want.reshape(-1) + np.uint32(0x9E3779B9) * idx
+        h ^= h >> 16; h *= np.uint32(0x85EBCA6B); h ^= h >> 13; h *= np.uint32(0xC2B2AE35); h ^= h >> 16
+        assert s.value == int(h.astype(np.uint64).sum(dtype=np.uint64))
+
+
+def test_cfg5_batched_4k_frames(csic, oracle):
+    """cfg 5 shape (3840x2160, 4:2:0, sf=4, Q_8BIT), 3 frames in one batched launch."""
+    import torch
+    W, H, n = 3840, 2160, 3
+    host_in = oracle.synth_frame(n * W * H, 0)
+    d_in = torch.from_numpy(host_in.view(np.int32)).cuda()
+    with _plan(csic, W, H, 2, 0, (3, 3, 2), 4) as pl:
+        d_out = pl.process_device(d_in, nframes=n)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().view(np.uint32)
+    for k in range(n):
+        want = oracle.process(_oparams(oracle, W, H, 2, 0, (3, 3, 2), 4), host_in[k * W * H:(k + 1) * W * H], form="closed")
+        assert np.array_equal(got[k], want)
+
+
+# ---- size-independent properties -------------------------------------------------------------------
+def test_row_stripes_reassemble(csic, oracle):
+    """Aligned row stripes are independent images: processing them separately == the full frame."""
+    W, H = 512, 384
+    argb = oracle.synth_frame(W * H, 99).reshape(H, W)
+    lib = csic._native.lib()
+    for (a, b, f, op) in [(2, 0, 1, CSQ), (2, 0, 2, CSQ), (1, 0, 4, CSQ), (2, 0, 2, (1, 3, 2)), (1, 1, 4, (1, 2, 3))]:
+        cp = csic.make_c_params(W, H, a, b, 3, 3, 2, f, op)
+        with csic.Plan(cp, 0) as pl:
+            full = pl.process_host(argb)
+        for nranks in (2, 3, 8):
+            parts = []
+            for rank in range(nranks):
+                r0, nr, o0, on = (C.c_int32() for _ in range(4))
+                csic._native.check(lib.csic_stripe_rows(C.byref(cp), nranks, rank, C.byref(r0), C.byref(nr), C.byref(o0), C.byref(on)))
+                if nr.value == 0:
+                    continue
+                scp = csic.make_c_params(W, nr.value, a, b, 3, 3, 2, f, op)
+                with csic.Plan(scp, 0) as spl:
+                    part = spl.process_host(argb[r0.value:r0.value + nr.value])
+                assert part.shape[0] == on.value
+                parts.append(part)
+            assert np.array_equal(np.concatenate(parts, 0), full), (a, b, f, op, nranks)
+
+
+def test_quantiser_idempotent_and_commutes(csic, oracle):
+    W, H = 256, 64
+    argb = oracle.synth_frame(W * H, 7)
+    outs = []
+    for op in ORDERS:
+        with _plan(csic, W, H, 2, 0, (3, 3, 2), 2, op, fmt=1) as pl:
+            outs.append((op, pl.process_host(argb)))
+    c_first = [o for op, o in outs if op.index(3) < op.index(1)]
+    s_first = [o for op, o in outs if op.index(1) < op.index(3)]
+    assert all(np.array_equal(c_first[0], o) for o in c_first)
+    assert all(np.array_equal(s_first[0], o) for o in s_first)
+    ycc = c_first[0]
+    assert np.all((ycc & 0xFF) % 32 == 0) and np.all(((ycc >> 8) & 0xFF) % 32 == 0) and np.all(((ycc >> 16) & 0xFF) % 64 == 0)
+
+
+def test_device_tensor_path_and_unaligned_pointer(csic, oracle):
+    import torch
+    W, H = 64, 32
+    argb = oracle.synth_frame(W * H, 5)
+    want = oracle.process(_oparams(oracle, W, H, 2, 0), argb)
+    top = csic.ImageCompressorTop(W, H, 2, 0, 8, 8, 8, 1, 3, 1, 2)
+    buf = torch.zeros(W * H + 1, dtype=torch.int32, device="cuda:0")
+    buf[1:] = torch.from_numpy(argb.view(np.int32)).cuda()
+    got = top.process(buf[1:].contiguous())                  # aligned copy
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want)
+    # 4-byte-aligned-only view: the vector kernel must not be used on it
+    pl = top.plan()
+    d_out = torch.empty(H * W + 1, dtype=torch.int32, device="cuda:0")
+    csic._native.check(csic._native.lib().csic_process_device(
+        pl._h, C.c_void_p(buf.data_ptr() + 4), C.c_void_p(d_out.data_ptr() + 4),
+        C.c_void_p(torch.cuda.current_stream(0).cuda_stream)))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out[1:].cpu().numpy().view(np.uint32).reshape(H, W), want)
+    top.close()
+
+
+def test_errors_on_device_path(csic):
+    with pytest.raises(csic.IllegalArgumentException):
+        csic.ImageCompressorTop(4, 4, 4, 4, 8, 8, 8, 3, 1, 2, 3)          # factor 3
+    with pytest.raises(csic.IllegalArgumentException):
+        csic.ImageCompressorTop(4, 4, 4, 4, 8, 8, 8, 2, 1, 1, 3)          # not a permutation
+    top = csic.ImageCompressorTop(8, 8, 4, 4, 8, 8, 8, 2, 1, 2, 3)
+    with pytest.raises(csic.IllegalArgumentException):
+        top.process(np.zeros(63, np.uint32))                               # wrong size
+    with pytest.raises(csic.CsicRuntimeError):
+        csic.Plan(csic.make_c_params(8, 8, 4, 4, 8, 8, 8, 1, CSQ), 99)    # no such device
+    top.close()
