@@ -18,7 +18,7 @@ ENODEVICE, EHIP, ENOMEM = -20, -21, -22
 OP_NOOP, OP_SPATIAL, OP_QUANT, OP_CHROMA = 0, 1, 2, 3
 ROUND_FLOOR_HW, ROUND_TRUNC_SW = 0, 1
 FMT_ARGB8888, FMT_YCBCR888X = 0, 1
-TUNE_VARIANT, TUNE_FORCE_GENERIC = 1, 2
+TUNE_VARIANT, TUNE_FORCE_GENERIC, TUNE_NONTEMPORAL = 1, 2, 3
 
 
 class IllegalArgumentException(ValueError):
@@ -84,6 +84,14 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C chroma-subsampling-image-compressor_amd/csrc`. There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and loads it by
+        # absolute path, so if libcsic_hip.so pulled in /opt/rocm's copy first the process would hold
+        # two runtimes and the second one sees no GPU.  Importing torch first makes our DT_NEEDED
+        # entry resolve (by soname) to the runtime torch already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in PROTOTYPES.items():
             fn = getattr(L, name)            # AttributeError here == ABI drift; keep it loud

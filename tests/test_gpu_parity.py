@@ -74,6 +74,9 @@ def test_random_shapes_vs_oracle(csic, oracle, seed):
             for variant in (1, 2):                      # 16-byte-load variants of the f=2 kernel
                 pl.tune(csic._native.TUNE_VARIANT, variant)
                 assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
+            pl.tune(csic._native.TUNE_VARIANT, 0)
+            pl.tune(csic._native.TUNE_NONTEMPORAL, 0)   # cached loads/stores instead of nt
+            assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
             pl.tune(csic._native.TUNE_FORCE_GENERIC, 1)
             assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
     assert {"k_f1x4", "k_dec", "k_generic"} <= seen

@@ -1,0 +1,22 @@
+#!/bin/bash
+# tools/profile.sh TAG -- run on the GPU box (via gpurun): rocprofv3 kernel trace + stats of bench.py and
+# the two PMC passes for HBM traffic (separate passes: FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2).
+# Outputs land in gpurun_out/prof_TAG/; tools/pmc_traffic.py condenses them into profiles/.
+set -o pipefail
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python3 $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace_bench.json" 2> "$OUT/trace.err" &&
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- $BENCH > "$OUT/fetch_bench.json" 2> "$OUT/fetch.err" &&
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- $BENCH > "$OUT/write_bench.json" 2> "$OUT/write.err" &&
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/calib_fetch" -o fetch -- python3 $ROOT/tools/pmc_calib.py > "$OUT/calib_fetch.log" 2>&1 &&
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/calib_write" -o write -- python3 $ROOT/tools/pmc_calib.py > "$OUT/calib_write.log" 2>&1
+rc=$?
+cd "$ROOT"
+find "$OUT" -name '*.csv' | head -50
+ls -la "$OUT"
+exit $rc
