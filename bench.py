@@ -194,10 +194,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                ent = tj.get(args.config, {}).get(plan.kernel_name)
-                if ent:
-                    traffic, traffic_note = ent["hbm_bytes_per_launch"], ent.get("note")
+                ent = json.load(open(tpath)).get(args.config)
+                if ent and ent.get("plan_kernel") == plan.kernel_name and world == 1:
+                    traffic, traffic_note = ent["hbm_bytes_per_launch"], f"profiles/pmc_traffic.json ({ent['tag']}): " + ent["note"]
             except Exception:
                 pass
         line = {

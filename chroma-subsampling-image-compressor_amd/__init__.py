@@ -9,8 +9,13 @@ from . import _native
 from ._native import CsicRuntimeError, IllegalArgumentException
 from .params import ImageProcessorParams, PixelFormat, ProcessingStep, Rounding, make_c_params
 from .compressor import ImageCompressorTop, ImageProcessor, Plan
+from .model import Image, ImageProcessorModel
+from .app import ImageCompressionApp
+from .distributed import Stripe, StripedImageCompressorTop, stripe_for_rank
+from . import app, compressor, distributed, model, params
 
 __all__ = [
     "CsicRuntimeError", "IllegalArgumentException", "ImageProcessorParams", "PixelFormat", "ProcessingStep",
-    "Rounding", "make_c_params", "ImageCompressorTop", "ImageProcessor", "Plan",
+    "Rounding", "make_c_params", "ImageCompressorTop", "ImageProcessor", "Plan", "Image", "ImageProcessorModel",
+    "ImageCompressionApp", "Stripe", "StripedImageCompressorTop", "stripe_for_rank",
 ]

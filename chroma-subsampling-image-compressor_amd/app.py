@@ -1,0 +1,103 @@
+"""Drop-in for `sbt "Test / runMain jpeg.ImageCompressionApp ..."`:
+
+    python -m csic_amd.app --input test_images/in128x128.png --a 2 --b 0 --sf 2 --op1 chroma --op2 spatial --op3 color
+
+ImageCompressionApp <- object ImageCompressionApp, src/test/scala/jpeg/ImageCompressorTopApp.scala:18-216
+Same flags (space-separated `--key value` pairs, :149-151), same defaults (:164-173; note sf = 8 and the
+order spatial, color, chroma), same banner, same output naming including the literal `order-Pr-Pr-Pr`
+tag (:188; ChiselEnum.toString quirk).  The simulated-RTL run is replaced by one fused
+HIP launch.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from typing import Dict, List
+
+import numpy as np
+
+from . import _native as N
+from .compressor import ImageCompressorTop
+from .model import Image, ImageProcessorModel
+from .params import ProcessingStep
+
+
+class ImageCompressionApp:
+    @staticmethod
+    def processImage(inputImagePath: str, outputImagePath: str,
+                     chromaParamA: int, chromaParamB: int,
+                     yTargetBits: int, cbTargetBits: int, crTargetBits: int,
+                     spatialFactorToUse: int,
+                     op1: ProcessingStep, op2: ProcessingStep, op3: ProcessingStep, *, device: int = 0) -> None:
+        """ImageCompressorTopApp.scala:23-145."""
+        inputImage = ImageProcessorModel.readImage(inputImagePath)
+        W, H = inputImage.width, inputImage.height
+        f = spatialFactorToUse
+        spatial_in = ProcessingStep.SpatialSampling in (op1, op2, op3)
+        top = ImageCompressorTop(W, H, chromaParamA, chromaParamB, yTargetBits, cbTargetBits, crTargetBits,
+                                 f, op1, op2, op3, device=device)
+        finalW = W // f if spatial_in else W                      # :44-45
+        finalH = H // f if spatial_in else H
+        if spatial_in and (W % f != 0 or H % f != 0):
+            print(f"[WARN] Image dimensions ({W}x{H}) are not perfectly divisible by spatialFactor ({f}). "
+                  "SpatialDownsampler might truncate.")                # :47-49
+        out = top.process(inputImage.argb)                           # (ceil(H/f), ceil(W/f)) stream, row-major
+        top.close()
+        # The harness collects the first finalW*finalH pixels of the OUTPUT STREAM and lays them out
+        # finalW per row (:108-124, :133-142); identical to `out` when the dimensions divide.
+        stream = out.reshape(-1)[: finalW * finalH]
+        if stream.size < finalW * finalH:
+            pad = np.full(finalW * finalH - stream.size, 0xFFFF00FF, dtype=np.uint32)   # AwtColor.MAGENTA fill, :133
+            stream = np.concatenate([stream, pad])
+        ImageProcessorModel.writeImage(Image(stream.reshape(finalH, finalW)), outputImagePath)
+
+
+def _order_tag(step: ProcessingStep) -> str:
+    # `${op.toString.split('.').last.take(2)}` on a ChiselEnum value "ProcessingStep(1=SpatialSampling)"
+    # yields "Pr" for every step (ImageCompressorTopApp.scala:188).
+    return f"ProcessingStep({int(step)}={step.name})".split(".")[-1][:2]
+
+
+def main(argv: List[str] = None) -> int:
+    args = list(sys.argv[1:] if argv is None else argv)
+    argsMap: Dict[str, str] = {}
+    for i in range(0, len(args) - 1, 2):                              # args.sliding(2, 2), :149-151
+        if args[i].startswith("--"):
+            argsMap[args[i]] = args[i + 1]
+    inputPath = argsMap.get("--input", "test_images/in128x128.png")
+    a = int(argsMap.get("--a", "4"))
+    b = int(argsMap.get("--b", "4"))
+    yq = int(argsMap.get("--yq", "8"))
+    cbq = int(argsMap.get("--cbq", "8"))
+    crq = int(argsMap.get("--crq", "8"))
+    sf = int(argsMap.get("--sf", "8"))
+    op1 = ProcessingStep.parse(argsMap.get("--op1", "spatial"))
+    op2 = ProcessingStep.parse(argsMap.get("--op2", "color"))
+    op3 = ProcessingStep.parse(argsMap.get("--op3", "chroma"))
+    imageName = os.path.basename(inputPath).split(".")[0]
+
+    print("----------------------------------------------------")
+    print("Image Compressor Application Parameters:")
+    print("----------------------------------------------------")
+    print(f"Input Image: {inputPath}")
+    print(f"Selected Chroma Subsampling (J:a:b): 4:{a}:{b}")
+    print(f"Selected Quantization Bits (Y/Cb/Cr): {yq}/{cbq}/{crq}")
+    print(f"Selected Spatial Downsampling Factor: {sf}")
+    print(f"Selected Pipeline Order: {op1.name} -> {op2.name} -> {op3.name}")
+    print("----------------------------------------------------")
+
+    outDir = argsMap.get("--outdir", "APP_OUTPUT")
+    order = f"order-{_order_tag(op1)}-{_order_tag(op2)}-{_order_tag(op3)}"
+    suffix = f"chroma4-{a}-{b}_Y{yq}Cb{cbq}Cr{crq}_sf{sf}_{order}"
+    outputPath = f"{outDir}/{imageName}_processed_{suffix}.png"
+    os.makedirs(outDir, exist_ok=True)
+    if not os.path.exists(inputPath):
+        print(f"[ERROR] Input image not found: {inputPath}")          # :197-199 (not an exception)
+        return 0
+    ImageCompressionApp.processImage(inputPath, outputPath, a, b, yq, cbq, crq, sf, op1, op2, op3)
+    print(f"Image processing complete. Output saved to: {outputPath}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,0 +1,110 @@
+"""Row-stripe data parallelism over the GPUs of one node: one process per GPU (torch.distributed,
+backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
+
+The reference has no multi-device code at all.  The path shards by contiguous row
+stripes of the INPUT; csic_stripe_rows aligns every boundary to L input rows (L = lcm(v, f) when chroma
+runs before the decimator, v*f*f when it runs behind it), which makes each stripe an independent
+image: the 4:2:0 odd-row hold (ChromaSubsampler.scala:52-65) only ever looks one row up, and that row
+is in the same stripe.  Hence NO data-path collective and no halo: the only communication is the
+optional gather of the finished output stripes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+from . import _native as N
+from .compressor import Plan
+from .params import PixelFormat, ProcessingStep, Rounding, make_c_params
+
+
+@dataclass(frozen=True)
+class Stripe:
+    rank: int
+    nranks: int
+    row0: int        # first input row owned by this rank
+    nrows: int       # number of input rows
+    out_row0: int    # first output row produced
+    out_nrows: int   # number of output rows
+
+
+def stripe_for_rank(c_params: N.CsicParams, nranks: int, rank: int) -> Stripe:
+    r0, nr, o0, on = (C.c_int32() for _ in range(4))
+    N.check(N.lib().csic_stripe_rows(C.byref(c_params), nranks, rank, C.byref(r0), C.byref(nr), C.byref(o0), C.byref(on)))
+    return Stripe(rank, nranks, r0.value, nr.value, o0.value, on.value)
+
+
+class StripedImageCompressorTop:
+    """ImageCompressorTop over a frame that is row-striped across the ranks of a process group.
+
+    Every rank constructs it with the GLOBAL frame parameters (same 11-argument list as
+    ImageCompressorTop.scala:11-25); `stripe` says which input rows this rank must supply to
+    process_local(), which returns this rank's output rows.  `plan_factory(c_params, device)` builds
+    the object whose .process(frame) does the work -- the HIP Plan by default; the CPU test-suite
+    injects an oracle-backed stand-in there to exercise the partition/gather logic without a GPU.
+    """
+
+    def __init__(self, width, height, chroma_param_a_config, chroma_param_b_config,
+                 yTargetQuantBitsConfig, cbTargetQuantBitsConfig, crTargetQuantBitsConfig, downFactorConfig,
+                 op1Type, op2Type, op3Type, *, rounding=Rounding.FLOOR_HW, out_format=PixelFormat.ARGB8888,
+                 group=None, device: Optional[int] = None,
+                 plan_factory: Callable[[N.CsicParams, int], object] = Plan):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.nranks = dist.get_world_size(group) if dist.is_initialized() else 1
+        ops = (ProcessingStep(op1Type), ProcessingStep(op2Type), ProcessingStep(op3Type))
+        self._gargs = (chroma_param_a_config, chroma_param_b_config, yTargetQuantBitsConfig,
+                       cbTargetQuantBitsConfig, crTargetQuantBitsConfig, downFactorConfig, ops)
+        self.global_params = make_c_params(width, height, *self._gargs, rounding=rounding, out_format=out_format)
+        N.check(N.lib().csic_validate(C.byref(self.global_params)))
+        self.stripe = stripe_for_rank(self.global_params, self.nranks, self.rank)
+        self.stripes = [stripe_for_rank(self.global_params, self.nranks, r) for r in range(self.nranks)]
+        wo, ho = C.c_int32(), C.c_int32()
+        N.check(N.lib().csic_out_dims(C.byref(self.global_params), C.byref(wo), C.byref(ho)))
+        self.out_width, self.out_height = wo.value, ho.value
+        self.device = self.rank if device is None else device
+        self._plan = None
+        if self.stripe.nrows > 0:
+            sp = make_c_params(width, self.stripe.nrows, *self._gargs, rounding=rounding, out_format=out_format)
+            self._plan = plan_factory(sp, self.device)
+
+    def process_local(self, local_rows):
+        """local_rows: this rank's input rows [row0, row0+nrows) (numpy uint32 or CUDA tensor, nrows x W).
+        Returns its output rows (out_nrows x out_width)."""
+        if self._plan is None:
+            return None
+        return self._plan.process(local_rows)
+
+    def gather(self, local_out, dst: int = 0):
+        """Assembles the full output frame on rank `dst` (None elsewhere).  Stripes are ragged, so they
+        are padded to the tallest one for the collective and trimmed afterwards."""
+        import torch
+        dist = self._dist
+        if self.nranks == 1:
+            return local_out
+        max_rows = max(s.out_nrows for s in self.stripes)
+        was_numpy = not hasattr(local_out, "is_cuda") and local_out is not None
+        if local_out is None:
+            t = None
+        elif was_numpy:
+            t = torch.from_numpy(local_out.view("int32").copy())
+        else:
+            t = local_out
+        ref = t if t is not None else None
+        dev = ref.device if ref is not None else torch.device("cpu")
+        pad = torch.zeros((max_rows, self.out_width), dtype=torch.int32, device=dev)
+        if t is not None:
+            pad[: t.shape[0]] = t.view(torch.int32).reshape(-1, self.out_width)
+        bufs = [torch.empty_like(pad) for _ in range(self.nranks)] if self.rank == dst else None
+        dist.gather(pad, bufs, dst=dst, group=self.group)
+        if self.rank != dst:
+            return None
+        full = torch.cat([b[: s.out_nrows] for b, s in zip(bufs, self.stripes)], 0)
+        return full.numpy().view("uint32") if dev.type == "cpu" else full
+
+    def close(self):
+        if self._plan is not None and hasattr(self._plan, "close"):
+            self._plan.close()

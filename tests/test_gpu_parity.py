@@ -254,3 +254,49 @@ def test_errors_on_device_path(csic):
     with pytest.raises(csic.CsicRuntimeError):
         csic.Plan(csic.make_c_params(8, 8, 4, 4, 8, 8, 8, 1, CSQ), 99)    # no such device
     top.close()
+
+
+# ---- the reference's own harness flows, end to end through the host mirror ---------------------------
+def test_app_cli_reproduces_app_golden(csic, tmp_path, manifest):
+    """`ImageCompressionApp --input in128x128.png --a 2 --b 2 --sf 2 --op1 chroma --op2 spatial --op3 color`
+    must write the same pixels, under the same file name, as the committed APP_OUTPUT golden."""
+    e = next(g for g in manifest["goldens"] if g["name"] == "app_422_888_sf2_128")
+    src = tmp_path / "in128x128.png"
+    src.write_bytes(open(os.path.join(GOLDEN, "inputs", "in128.png"), "rb").read())
+    rc = csic.app.main(["--input", str(src), "--a", "2", "--b", "2", "--sf", "2", "--op1", "chroma",
+                        "--op2", "spatial", "--op3", "color", "--outdir", str(tmp_path / "APP_OUTPUT")])
+    assert rc == 0
+    out = tmp_path / "APP_OUTPUT" / os.path.basename(e["ref_path"])       # ..._sf2_order-Pr-Pr-Pr.png
+    assert out.exists(), os.listdir(tmp_path / "APP_OUTPUT")
+    assert np.array_equal(load_png_rgb(str(out)), load_png_rgb(os.path.join(GOLDEN, e["file"])))
+
+
+def test_image_processor_integration_flow(csic, input_images, manifest):
+    """SpatialDownsamplerSpec.scala:155-230: in16x16 -> ImageProcessorParams(w,h,2,2,0) -> ImageProcessor
+    -> 8x8; pixels pinned by APP_OUTPUT/spatial_downsampler_integration_420_sf2.png."""
+    e = next(g for g in manifest["goldens"] if g["name"] == "ip_420_sf2_16")
+    img = csic.Image.from_rgb(input_images["in16"])
+    params = csic.ImageProcessorParams(width=img.width, height=img.height, factor=2, chromaParamA=2, chromaParamB=0)
+    dut = csic.ImageProcessor(params)
+    out = dut.process(img.argb)
+    dut.close()
+    assert out.shape == (8, 8)
+    assert np.array_equal(csic.Image(out).rgb(), load_png_rgb(os.path.join(GOLDEN, e["file"])))
+
+
+def test_app_non_divisible_collects_truncated_stream(csic, oracle, tmp_path):
+    """Non-divisible sizes: the RTL emits ceil(W/f)*ceil(H/f) pixels but the app collects only
+    (W/f)*(H/f) of them, finalW per row, and warns (ImageCompressorTopApp.scala:44-49,108-124)."""
+    from PIL import Image as PILImage
+    W, H, f = 21, 13, 4
+    rgb = oracle.argb_to_rgb(oracle.synth_frame(W * H, 3).reshape(H, W))
+    src = tmp_path / "odd.png"
+    PILImage.fromarray(rgb, "RGB").save(src)
+    dst = tmp_path / "odd_out.png"
+    PS = csic.ProcessingStep
+    csic.ImageCompressionApp.processImage(str(src), str(dst), 2, 0, 8, 8, 8, f, PS.ChromaSubsampling,
+                                          PS.SpatialSampling, PS.ColorQuantization)
+    stream = oracle.process(oracle.OracleParams(width=W, height=H, chroma_a=2, chroma_b=0, factor=f),
+                            oracle.rgb_to_argb(rgb)).reshape(-1)
+    want = oracle.argb_to_rgb(stream[: (W // f) * (H // f)].reshape(H // f, W // f))
+    assert np.array_equal(load_png_rgb(str(dst)), want)

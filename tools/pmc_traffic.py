@@ -52,6 +52,42 @@ def main():
         json.dump(summary, fh, indent=1)
     print(json.dumps(summary, indent=1))
 
+    # ---- corrected HBM bytes per launch of the bench kernel -> profiles/pmc_traffic.json ----------
+    # Calibration on known byte counts (same session, same access widths as the product kernels):
+    #   k_checksum reads N bytes with dense 4-byte loads  -> FETCH_SIZE*1024 should be N/2 (gfx950: x2)
+    #   k_synth writes N bytes with dense 4-byte stores   -> WRITE_SIZE*1024 should be N   (exact)
+    N = 8192 * 8192 * 4
+    ck = next((v for k, v in summary["calibration"].items() if "k_checksum" in k), None)
+    sy = next((v for k, v in summary["calibration"].items() if "k_synth" in k), None)
+    fetch_scale = N / (ck["FETCH_SIZE_mean"] * 1024) if ck and ck["FETCH_SIZE_mean"] else 2.0
+    write_scale = N / (sy["WRITE_SIZE_mean"] * 1024) if sy and sy["WRITE_SIZE_mean"] else 1.0
+    bench_json = os.path.join(src, "fetch_bench.json")
+    plan_kernel = None
+    if os.path.exists(bench_json):
+        try:
+            plan_kernel = json.load(open(bench_json))["config"]["kernel"]
+        except Exception:
+            pass
+    tpath = os.path.join(dst, "pmc_traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    for k, v in summary["bench"].items():
+        if "k_synth" in k or v["FETCH_SIZE_mean"] is None or v["WRITE_SIZE_mean"] is None:
+            continue
+        rd = v["FETCH_SIZE_mean"] * 1024 * 2.0          # guide's gfx950 correction 
+        wr = v["WRITE_SIZE_mean"] * 1024 * 1.0
+        traffic[config] = {
+            "plan_kernel": plan_kernel, "rocprof_kernel": k, "tag": tag,
+            "hbm_read_bytes_per_launch": round(rd), "hbm_write_bytes_per_launch": round(wr),
+            "hbm_bytes_per_launch": round(rd + wr),
+            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB units); read side x2 per "
+                    "MI355X_MICROARCH.md (gfx950 FETCH_SIZE tallies 128-B requests at 64 B), write side x1; "
+                    f"calibrated in the same session on known byte counts: k_checksum read scale {fetch_scale:.4f}, "
+                    f"k_synth write scale {write_scale:.4f}",
+        }
+    with open(tpath, "w") as fh:
+        json.dump(traffic, fh, indent=1)
+    print(json.dumps(traffic, indent=1))
+
 
 if __name__ == "__main__":
     main()
