@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (CSIC_TUNE_VARIANT); -1 = library default")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--ring-mib", type=int, default=2048, help="input bytes rotated through (MiB), per GPU")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N>1; gloo only to rehearse the N>1 path on a 1-GPU box "
+                         "(ranks then share GPU local_rank %% device_count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = ap.parse_args()
@@ -103,10 +106,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)            # RCCL; barrier + max-reduce only
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)        # RCCL; barrier + max-reduce only
+        else:
+            dist.init_process_group("gloo")
 
     W, H, a, b, bits, f, fps = CONFIGS[args.config]
     # ---- this rank's stripe ---------------------------------------------------------------------
@@ -115,7 +122,7 @@ def main():
     r0, nr, o0, on = (C.c_int32() for _ in range(4))
     N.check(lib.csic_stripe_rows(C.byref(gparams), world, rank, C.byref(r0), C.byref(nr), C.byref(o0), C.byref(on)))
     sH = nr.value
-    plan = csic.Plan(csic.make_c_params(W, sH, a, b, *bits, f, CSQ), local_rank)
+    plan = csic.Plan(csic.make_c_params(W, sH, a, b, *bits, f, CSQ), dev_index)
     if args.variant >= 0:
         plan.tune(N.TUNE_VARIANT, args.variant)
     in_px, out_px = W * sH, plan.out_width * plan.out_height
@@ -169,7 +176,7 @@ def main():
         N.check(step(0))
         raise SystemExit("a launch failed inside the timed region")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms_avg = ev0.elapsed_time(ev1) / K

@@ -226,15 +226,18 @@ __global__ void __launch_bounds__(256) k_dec(KArgs a)
     const int bx = blockDim.x;
     const int cbase = blockIdx.x * (bx * K);
     const int co0 = cbase + threadIdx.x;
-    const bool full = cbase + bx * K <= a.Wo;           // uniform over the block
     const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
     uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
     const int row_step = gridDim.y * blockDim.y;
-    for (int ro = blockIdx.y * blockDim.y + threadIdx.y; ro < a.Ho; ro += row_step) {
-        const uint32_t *rowp = in + (int64_t)(ro * F) * a.W;
-        uint32_t *orow = out + (int64_t)ro * a.Wo;
-        if (full) dec_chunk<ROUND, FMT, F, HGTF, K, NT, false>(a, rowp, orow, co0, bx);
-        else      dec_chunk<ROUND, FMT, F, HGTF, K, NT, true>(a, rowp, orow, co0, bx);
+    const int ro0 = blockIdx.y * blockDim.y + threadIdx.y;
+    // two separate row loops (the condition is uniform over the block) so that the fast path keeps
+    // its own straight-line load/store sequence
+    if (cbase + bx * K <= a.Wo) {
+        for (int ro = ro0; ro < a.Ho; ro += row_step)
+            dec_chunk<ROUND, FMT, F, HGTF, K, NT, false>(a, in + (int64_t)(ro * F) * a.W, out + (int64_t)ro * a.Wo, co0, bx);
+    } else {
+        for (int ro = ro0; ro < a.Ho; ro += row_step)
+            dec_chunk<ROUND, FMT, F, HGTF, K, NT, true>(a, in + (int64_t)(ro * F) * a.W, out + (int64_t)ro * a.Wo, co0, bx);
     }
 }
 

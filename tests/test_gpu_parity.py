@@ -300,3 +300,31 @@ def test_app_non_divisible_collects_truncated_stream(csic, oracle, tmp_path):
                             oracle.rgb_to_argb(rgb)).reshape(-1)
     want = oracle.argb_to_rgb(stream[: (W // f) * (H // f)].reshape(H // f, W // f))
     assert np.array_equal(load_png_rgb(str(dst)), want)
+
+
+def test_process_device_is_hipgraph_capturable(csic, oracle):
+    """csic_process_device allocates nothing and never synchronises, so per-frame launches can be
+    captured into a hipGraph and replayed (BASELINE cfg 5 asks for a graph-captured per-frame launch)."""
+    import torch
+    W, H, n = 960, 540, 4
+    host_in = oracle.synth_frame(n * W * H, 77)
+    d_in = torch.from_numpy(host_in.view(np.int32)).cuda()
+    with _plan(csic, W, H, 2, 0, (3, 3, 2), 4) as pl:
+        d_out = torch.zeros(n * pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0")
+        ipx, opx = W * H, pl.out_width * pl.out_height
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            pl.process_device(d_in[:ipx], d_out[:opx])                      # warm-up outside capture
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for k in range(n):
+                pl.process_device(d_in[k * ipx:(k + 1) * ipx], d_out[k * opx:(k + 1) * opx])
+        d_out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().view(np.uint32).reshape(n, pl.out_height, pl.out_width)
+    for k in range(n):
+        want = oracle.process(_oparams(oracle, W, H, 2, 0, (3, 3, 2), 4), host_in[k * ipx:(k + 1) * ipx], form="closed")
+        assert np.array_equal(got[k], want)
