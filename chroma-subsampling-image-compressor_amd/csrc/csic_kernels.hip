@@ -43,7 +43,8 @@ struct KArgs {
     int32_t W, H, Wo, Ho;
     int32_t last_sample_col;
     uint32_t my, mcb, mcr;
-    int32_t f, hmask, vmask, s_first;   // generic kernel only (hmask = h-1, vmask = v-1)
+    int32_t f, hmask, vmask, s_first;   // hmask = h-1, vmask = v-1 (generic kernel; vmask also k_dec SROWS)
+    int32_t sc_shift, bc_row_off, bc_col_in;   // k_dec SROWS: log2 f; held-sample decimated row offset / input column
     int64_t in_frame_px, out_frame_px;  // batch strides (grid z = frame)
 };
 
@@ -190,37 +191,85 @@ __global__ void __launch_bounds__(256) k_f1x4(KArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_dec: factor F in {2,4,8}, chroma before spatial.  K output pixels per lane.
-// With h <= F every surviving pixel is its own chroma sample; the one
-// exception is 4:1:1 with F = 2 (HGTF): chroma comes from column (c & ~3).
+// k_dec: factor F in {2,4,8}, both order classes.  K output pixels per lane.
+//
+// Chroma source of output pixel (ro, co), in DECIMATED coordinates:
+//   chroma before spatial: the hold runs on image columns c = co*F: source column c - c % h.  With
+//     h <= F that is the pixel itself (the chroma stage is unobservable); the one
+//     exception, 4:1:1 with F = 2, is decimated column co & ~1.  Rows ro*F are always sample rows.
+//   spatial before chroma (SROWS): the chroma counters run on the decimated stream modulo the FULL
+//     width W (ImageCompressorTop.scala:52-58).  When F | W and h | Wo, chroma row r = ro / F; on
+//     r % v == 0 the source is decimated column co & ~(h-1) of the same row; on odd r (4:x:0) every
+//     pixel of the F decimated rows replays ONE pixel: the last sample of chroma row r-1.
+// In both classes the in-row hold is a lane shuffle inside an aligned quad (HOLD in {1,2,4} lanes):
+// one v_mov_b32 DPP quad_perm on the loaded pixel instead of a second gather.
 // ------------------------------------------------------------------------------------------------
+template <int HOLD>
+__device__ __forceinline__ uint32_t hold_in_quad(uint32_t v)
+{
+    if (HOLD == 2) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xA0 /* quad_perm:[0,0,2,2] */, 0xF, 0xF, false);
+    if (HOLD == 4) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x00 /* quad_perm:[0,0,0,0] */, 0xF, 0xF, false);
+    return v;
+}
+
 // One row-chunk of k_dec.  CHECK = false is the block-uniform fast path (the whole chunk is inside the
 // row): K independent loads are issued back to back, then K stores, with no per-lane branches -- with
 // per-lane bounds checks hipcc wraps every access in its own exec-mask region and puts
 // s_waitcnt vmcnt(0) in front of every store, which serialises the stores (38.0 vs 32.7 us per frame).
-template <int ROUND, int FMT, int F, bool HGTF, int K, bool NT, bool CHECK>
-__device__ __forceinline__ void dec_chunk(const KArgs &a, const uint32_t *rowp, uint32_t *orow, int co0, int bx)
+// BCAST: the whole row replays one chroma pixel (`bpx`).
+template <int ROUND, int FMT, int F, int HOLD, bool BCAST, int K, bool NT, bool CHECK>
+__device__ __forceinline__ void dec_chunk(const KArgs &a, const uint32_t *rowp, uint32_t *orow, int co0, int bx,
+                                          uint32_t bpx)
 {
-    uint32_t px[K], cpx[K];
+    uint32_t px[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int co = co0 + k * bx;
-        if (!CHECK || co < a.Wo) {
-            px[k] = ld1<NT>(rowp + co * F);
-            cpx[k] = HGTF ? rowp[(co * F) & ~3] : px[k];   // neighbour in the same 16 B: plain (cached) load
-        }
+        if (!CHECK || co < a.Wo) px[k] = ld1<NT>(rowp + co * F);
     }
+    if (BCAST) {
+        const ChromaTerm t = chroma_term<ROUND, FMT>(bpx, a.mcb, a.mcr);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int co = co0 + k * bx;
-        if (!CHECK || co < a.Wo) {
-            const ChromaTerm t = chroma_term<ROUND, FMT>(cpx[k], a.mcb, a.mcr);
-            st1<NT>(orow + co, finish<FMT>(px[k], a.my, t));
+        for (int k = 0; k < K; ++k) {
+            const int co = co0 + k * bx;
+            if (!CHECK || co < a.Wo) st1<NT>(orow + co, finish<FMT>(px[k], a.my, t));
+        }
+    } else {
+        uint32_t cpx[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) cpx[k] = hold_in_quad<HOLD>(px[k]);   // all lanes; a source lane <= its reader
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int co = co0 + k * bx;
+            if (!CHECK || co < a.Wo) {
+                const ChromaTerm t = chroma_term<ROUND, FMT>(cpx[k], a.mcb, a.mcr);
+                st1<NT>(orow + co, finish<FMT>(px[k], a.my, t));
+            }
         }
     }
 }
 
-template <int ROUND, int FMT, int F, bool HGTF, int K, bool NT>
+template <int ROUND, int FMT, int F, int HOLD, bool SROWS, int K, bool NT, bool CHECK>
+__device__ __forceinline__ void dec_rows(const KArgs &a, const uint32_t *in, uint32_t *out, int co0, int bx,
+                                         int ro0, int row_step)
+{
+    for (int ro = ro0; ro < a.Ho; ro += row_step) {
+        const uint32_t *rowp = in + (int64_t)(ro * F) * a.W;
+        uint32_t *orow = out + (int64_t)ro * a.Wo;
+        if (SROWS) {
+            const int r = ro >> a.sc_shift;                               // chroma row = ro / F
+            if (r & a.vmask) {                                            // odd chroma row of 4:x:0
+                const int srow = ((r - 1) << a.sc_shift) + a.bc_row_off; // decimated row of the held sample
+                const uint32_t bpx = in[(int64_t)(srow * F) * a.W + a.bc_col_in];
+                dec_chunk<ROUND, FMT, F, HOLD, true, K, NT, CHECK>(a, rowp, orow, co0, bx, bpx);
+                continue;
+            }
+        }
+        dec_chunk<ROUND, FMT, F, HOLD, false, K, NT, CHECK>(a, rowp, orow, co0, bx, 0u);
+    }
+}
+
+template <int ROUND, int FMT, int F, int HOLD, bool SROWS, int K, bool NT>
 __global__ void __launch_bounds__(256) k_dec(KArgs a)
 {
     const int bx = blockDim.x;
@@ -232,13 +281,8 @@ __global__ void __launch_bounds__(256) k_dec(KArgs a)
     const int ro0 = blockIdx.y * blockDim.y + threadIdx.y;
     // two separate row loops (the condition is uniform over the block) so that the fast path keeps
     // its own straight-line load/store sequence
-    if (cbase + bx * K <= a.Wo) {
-        for (int ro = ro0; ro < a.Ho; ro += row_step)
-            dec_chunk<ROUND, FMT, F, HGTF, K, NT, false>(a, in + (int64_t)(ro * F) * a.W, out + (int64_t)ro * a.Wo, co0, bx);
-    } else {
-        for (int ro = ro0; ro < a.Ho; ro += row_step)
-            dec_chunk<ROUND, FMT, F, HGTF, K, NT, true>(a, in + (int64_t)(ro * F) * a.W, out + (int64_t)ro * a.Wo, co0, bx);
-    }
+    if (cbase + bx * K <= a.Wo) dec_rows<ROUND, FMT, F, HOLD, SROWS, K, NT, false>(a, in, out, co0, bx, ro0, row_step);
+    else                        dec_rows<ROUND, FMT, F, HOLD, SROWS, K, NT, true>(a, in, out, co0, bx, ro0, row_step);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,12 +435,37 @@ static KernelFn pick_f1x4(int h, int v)
 
 constexpr int DEC_K = 4;
 
-template <int ROUND, int FMT, bool NT>
-static KernelFn pick_dec(int f, bool hgtf)
+template <int ROUND, int FMT, int F, bool NT>
+static KernelFn pick_dec_f(int hold, bool srows)
 {
-    if (f == 2) return hgtf ? (KernelFn)k_dec<ROUND, FMT, 2, true, DEC_K, NT> : (KernelFn)k_dec<ROUND, FMT, 2, false, DEC_K, NT>;
-    if (f == 4) return k_dec<ROUND, FMT, 4, false, DEC_K, NT>;
-    return k_dec<ROUND, FMT, 8, false, DEC_K, NT>;
+    if (srows) {
+        if (hold == 1) return k_dec<ROUND, FMT, F, 1, true, DEC_K, NT>;
+        if (hold == 2) return k_dec<ROUND, FMT, F, 2, true, DEC_K, NT>;
+        return k_dec<ROUND, FMT, F, 4, true, DEC_K, NT>;
+    }
+    if (hold == 1) return k_dec<ROUND, FMT, F, 1, false, DEC_K, NT>;
+    if (hold == 2) return k_dec<ROUND, FMT, F, 2, false, DEC_K, NT>;
+    return k_dec<ROUND, FMT, F, 4, false, DEC_K, NT>;
+}
+
+template <int ROUND, int FMT, bool NT>
+static KernelFn pick_dec(int f, int hold, bool srows)
+{
+    if (f == 2) return pick_dec_f<ROUND, FMT, 2, NT>(hold, srows);
+    if (f == 4) return pick_dec_f<ROUND, FMT, 4, NT>(hold, srows);
+    return pick_dec_f<ROUND, FMT, 8, NT>(hold, srows);
+}
+
+// Can the k_dec family handle this geometry?  Chroma before spatial: always, except that a hold across
+// lanes (4:1:1 with f = 2) needs whole quads in a row.  Spatial before chroma: only when chroma rows
+// coincide with groups of decimated rows (f | W) and the in-row hold is lane-aligned (h | Wo).
+static bool dec_fast_ok(const Geometry &g)
+{
+    const int hold = g.s_first ? g.h : (g.h > g.f ? g.h / g.f : 1);
+    const int lanes_x = (g.Wo + DEC_K - 1) / DEC_K;
+    if (hold > 1 && lanes_x < 3) return false;            // block width < 4 lanes: quads would span rows
+    if (!g.s_first) return true;
+    return (g.W % g.f == 0) && (g.Wo % g.h == 0);
 }
 
 template <int ROUND, int FMT>
@@ -413,9 +482,11 @@ static void select_rf(csic_plan *pl)
         pl->units_per_row = g.W / 4;
         pl->k_per_lane = 1;
         snprintf(pl->name, sizeof pl->name, "k_f1x4<%s,%s,h%d,v%d,%s>", rn, fn, g.h, g.v, ntn);
-    } else if (!pl->force_generic && g.f > 1 && !g.s_first) {
-        const bool hgtf = g.h > g.f;
-        if (g.f == 2 && !hgtf && g.W % 8 == 0 && (pl->variant == 1 || pl->variant == 2)) {
+    } else if (!pl->force_generic && g.f > 1 && dec_fast_ok(g)) {
+        // in-row chroma hold distance in decimated lanes; srows = chroma rows follow the decimated stream
+        const bool srows = g.s_first != 0;
+        const int hold = srows ? g.h : (g.h > g.f ? g.h / g.f : 1);
+        if (g.f == 2 && hold == 1 && !srows && g.W % 8 == 0 && (pl->variant == 1 || pl->variant == 2)) {
             pl->fam = pl->variant == 1 ? FAM_DEC2V1 : FAM_DEC2V2;
             if (pl->variant == 1) pl->fn = nt ? (KernelFn)k_dec2v<ROUND, FMT, 1, true> : (KernelFn)k_dec2v<ROUND, FMT, 1, false>;
             else                  pl->fn = nt ? (KernelFn)k_dec2v<ROUND, FMT, 2, true> : (KernelFn)k_dec2v<ROUND, FMT, 2, false>;
@@ -424,10 +495,12 @@ static void select_rf(csic_plan *pl)
             snprintf(pl->name, sizeof pl->name, "k_dec2v<%s,%s,var%d,%s>", rn, fn, pl->variant, ntn);
         } else {
             pl->fam = FAM_DEC;
-            pl->fn = nt ? pick_dec<ROUND, FMT, true>(g.f, hgtf) : pick_dec<ROUND, FMT, false>(g.f, hgtf);
+            pl->fn = nt ? pick_dec<ROUND, FMT, true>(g.f, hold, srows && g.v == 2)
+                        : pick_dec<ROUND, FMT, false>(g.f, hold, srows && g.v == 2);
             pl->units_per_row = g.Wo;
             pl->k_per_lane = DEC_K;
-            snprintf(pl->name, sizeof pl->name, "k_dec<%s,%s,f%d,%s,K%d,%s>", rn, fn, g.f, hgtf ? "h>f" : "h<=f", DEC_K, ntn);
+            snprintf(pl->name, sizeof pl->name, "k_dec<%s,%s,f%d,hold%d,%s,K%d,%s>", rn, fn, g.f, hold,
+                     srows ? (g.v == 2 ? "s>c,v2" : "s>c") : "c>s", DEC_K, ntn);
         }
     } else {
         pl->fam = FAM_GENERIC;
@@ -487,6 +560,9 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
     a.f = g.f; a.hmask = g.h - 1; a.vmask = g.v - 1; a.s_first = g.s_first;
     a.in_frame_px = (int64_t)g.W * g.H;
     a.out_frame_px = (int64_t)g.Wo * g.Ho;
+    a.sc_shift = (g.f == 8) ? 3 : (g.f == 4) ? 2 : (g.f == 2) ? 1 : 0;
+    a.bc_row_off = g.last_sample_col / g.Wo;             // only meaningful (and only used) when f | W
+    a.bc_col_in = (g.last_sample_col % g.Wo) * g.f;
 
     const int rows = (fam == FAM_F1X4) ? g.H : g.Ho;
     const int lanes_x = (units + kpl - 1) / kpl;

@@ -328,3 +328,43 @@ def test_process_device_is_hipgraph_capturable(csic, oracle):
     for k in range(n):
         want = oracle.process(_oparams(oracle, W, H, 2, 0, (3, 3, 2), 4), host_in[k * ipx:(k + 1) * ipx], form="closed")
         assert np.array_equal(got[k], want)
+
+
+@pytest.mark.parametrize("a,b", [(4, 4), (2, 2), (2, 0), (1, 1), (1, 0), (4, 0)])
+@pytest.mark.parametrize("f", [2, 4, 8])
+def test_spatial_before_chroma_fast_path(csic, oracle, a, b, f):
+    """The reference app's DEFAULT order is spatial -> color -> chroma (ImageCompressorTopApp.scala:171-173):
+    chroma then runs on the decimated stream with counters modulo the full width.  1024x192 satisfies
+    f | W and h | Wo, so the k_dec family (DPP quad hold + per-row broadcast) must be selected."""
+    W, H = 1024, 192
+    argb = oracle.synth_frame(W * H, 2024)
+    for op in [(1, 2, 3), (1, 3, 2), (2, 1, 3)]:
+        for rounding in (0, 1):
+            want = oracle.process(_oparams(oracle, W, H, a, b, (6, 5, 5), f, op, rounding), argb, form="stream")
+            with _plan(csic, W, H, a, b, (6, 5, 5), f, op, rounding) as pl:
+                assert pl.kernel_name.startswith("k_dec<") and "s>c" in pl.kernel_name, pl.kernel_name
+                assert np.array_equal(pl.process_host(argb), want), pl.kernel_name
+
+
+def test_411_sf2_uses_quad_hold(csic, oracle):
+    """4:1:1 with f = 2, chroma before spatial: the only h > f case; chroma comes from decimated lane co & ~1."""
+    W, H = 2048, 64
+    argb = oracle.synth_frame(W * H, 11)
+    want = oracle.process(_oparams(oracle, W, H, 1, 1, (8, 8, 8), 2), argb)
+    with _plan(csic, W, H, 1, 1, (8, 8, 8), 2) as pl:
+        assert "hold2" in pl.kernel_name
+        assert np.array_equal(pl.process_host(argb), want)
+    for Wt in (4, 6, 10, 22):                      # narrow frames: block rows narrower than a quad -> generic
+        argb = oracle.synth_frame(Wt * 8, 5)
+        want = oracle.process(_oparams(oracle, Wt, 8, 1, 1, (8, 8, 8), 2), argb)
+        with _plan(csic, Wt, 8, 1, 1, (8, 8, 8), 2) as pl:
+            assert np.array_equal(pl.process_host(argb), want), (Wt, pl.kernel_name)
+
+
+def test_app_default_order_sf8(csic, oracle, input_images):
+    """`ImageCompressionApp` with no flags: in128x128, 4:4:4, 8/8/8, sf=8, spatial->color->chroma."""
+    argb = oracle.rgb_to_argb(input_images["in128"])
+    want = oracle.process(_oparams(oracle, 128, 128, 4, 4, (8, 8, 8), 8, (1, 2, 3)), argb)
+    top = csic.ImageCompressorTop(128, 128, 4, 4, 8, 8, 8, 8, 1, 2, 3)
+    assert np.array_equal(top.process(argb), want)
+    top.close()

@@ -179,7 +179,7 @@ int main()
     B.run("copy 256MiB->256MiB (x4, 2048 blk)", [&](int i) { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, (const u32x4 *)B.in[i], (u32x4 *)B.in[(i + 1) % B.nring], (int64_t)B.W * B.H / 4); }, 2.0 * 268435456.0);
     B.run("copy 256MiB->256MiB (x4, 65536 blk)", [&](int i) { hipLaunchKernelGGL(k_copy, dim3(65536), dim3(256), 0, 0, (const u32x4 *)B.in[i], (u32x4 *)B.in[(i + 1) % B.nring], (int64_t)B.W * B.H / 4); }, 2.0 * 268435456.0);
     // shipped kernels (as launched by the library: 256x1 blocks, gy = Ho)
-    B.run("shipped k_dec K4        grid 4x4096", L((k_dec<R_FLOOR, F_ARGB, 2, false, 4, false>), dim3(4, 4096), dim3(256)));
+    B.run("shipped k_dec K4        grid 4x4096", L((k_dec<R_FLOOR, F_ARGB, 2, 1, false, 4, false>), dim3(4, 4096), dim3(256)));
     B.run("shipped k_dec2v var1    grid 8x4096", L((k_dec2v<R_FLOOR, F_ARGB, 1, false>), dim3(8, 4096), dim3(256)));
     B.run("shipped k_dec2v var2    grid 4x4096", L((k_dec2v<R_FLOOR, F_ARGB, 2, false>), dim3(4, 4096), dim3(256)));
     // E1: memory-only vs compute, nt flags
@@ -227,7 +227,7 @@ int main()
     B.run("E7 512thr compute ntL ntS grid 2x4096", L((k_e7<true, true, true>), dim3(2, 4096), dim3(512)));
     B.run("E7 1024thr compute ntL ntS grid 1x4096", L((k_e7<true, true, true>), dim3(1, 4096), dim3(1024)));
 
-    B.run("shipped k_dec K4 nt     grid 4x4096", L((k_dec<R_FLOOR, F_ARGB, 2, false, 4, true>), dim3(4, 4096), dim3(256)));
+    B.run("shipped k_dec K4 nt     grid 4x4096", L((k_dec<R_FLOOR, F_ARGB, 2, 1, false, 4, true>), dim3(4, 4096), dim3(256)));
     B.run("shipped k_dec2v var2 nt grid 4x4096", L((k_dec2v<R_FLOOR, F_ARGB, 2, true>), dim3(4, 4096), dim3(256)));
     return 0;
 }
