@@ -46,7 +46,20 @@ struct KArgs {
     int32_t f, hmask, vmask, s_first;   // hmask = h-1, vmask = v-1 (generic kernel; vmask also k_dec SROWS)
     int32_t sc_shift, bc_row_off, bc_col_in;   // k_dec SROWS: log2 f; held-sample decimated row offset / input column
     int64_t in_frame_px, out_frame_px;  // batch strides (grid z = frame)
+    int32_t bdx, bdy, row_step;         // block width/height and gridDim.y * bdy, passed explicitly (see pin_args)
 };
+
+// Wave prologue.  hipcc sinks every kernel-argument s_load to its first use, and blockDim/gridDim come
+// from the hidden-argument area, so a kernel with early exits pays 3-4 DEPENDENT scalar-load round
+// trips (~0.4 us) before its first global load -- 5 % of the f=1 kernel, whose waves hold a single
+// 16-byte load in flight.  Pinning the arguments in SGPRs at entry turns that into one batch and one
+// s_waitcnt; the launch geometry travels in KArgs for the same reason.
+__device__ __forceinline__ void pin_args(const KArgs &a)
+{
+    asm volatile("" ::"s"(a.in), "s"(a.out), "s"(a.W), "s"(a.H), "s"(a.Wo), "s"(a.Ho), "s"(a.last_sample_col));
+    asm volatile("" ::"s"(a.my), "s"(a.mcb), "s"(a.mcr), "s"(a.in_frame_px), "s"(a.out_frame_px), "s"(a.bdx),
+                 "s"(a.bdy), "s"(a.row_step));
+}
 
 enum { R_FLOOR = CSIC_ROUND_FLOOR_HW, R_TRUNC = CSIC_ROUND_TRUNC_SW };
 enum { F_ARGB = CSIC_FMT_ARGB8888, F_YCC = CSIC_FMT_YCBCR888X };
@@ -159,13 +172,14 @@ __device__ __forceinline__ uint32_t finish(uint32_t ypx, uint32_t my, const Chro
 template <int ROUND, int FMT, int HH, int VV, bool NT>
 __global__ void __launch_bounds__(256) k_f1x4(KArgs a)
 {
+    pin_args(a);
     const int W4 = a.W >> 2;
-    const int x4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x4 = blockIdx.x * a.bdx + threadIdx.x;
     if (x4 >= W4) return;
     const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
     uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
-    const int row_step = gridDim.y * blockDim.y;
-    for (int row = blockIdx.y * blockDim.y + threadIdx.y; row < a.H; row += row_step) {
+    const int row_step = a.row_step;
+    for (int row = blockIdx.y * a.bdy + threadIdx.y; row < a.H; row += row_step) {
         const int64_t base = (int64_t)row * a.W + 4 * x4;
         const u32x4 p = ld4<NT>(in + base);
         const uint32_t px[4] = {p.x, p.y, p.z, p.w};
@@ -272,13 +286,14 @@ __device__ __forceinline__ void dec_rows(const KArgs &a, const uint32_t *in, uin
 template <int ROUND, int FMT, int F, int HOLD, bool SROWS, int K, bool NT>
 __global__ void __launch_bounds__(256) k_dec(KArgs a)
 {
-    const int bx = blockDim.x;
+    pin_args(a);
+    const int bx = a.bdx;
     const int cbase = blockIdx.x * (bx * K);
     const int co0 = cbase + threadIdx.x;
     const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
     uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
-    const int row_step = gridDim.y * blockDim.y;
-    const int ro0 = blockIdx.y * blockDim.y + threadIdx.y;
+    const int row_step = a.row_step;
+    const int ro0 = blockIdx.y * a.bdy + threadIdx.y;
     // two separate row loops (the condition is uniform over the block) so that the fast path keeps
     // its own straight-line load/store sequence
     if (cbase + bx * K <= a.Wo) dec_rows<ROUND, FMT, F, HOLD, SROWS, K, NT, false>(a, in, out, co0, bx, ro0, row_step);
@@ -296,13 +311,14 @@ template <int ROUND, int FMT, int VAR, bool NT>
 __global__ void __launch_bounds__(256) k_dec2v(KArgs a)
 {
     constexpr int OPL = (VAR == 1) ? 2 : 4;             // output pixels per lane
+    pin_args(a);
     const int nx = a.Wo / OPL;                          // lanes per row (W % 8 == 0 -> exact)
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = blockIdx.x * a.bdx + threadIdx.x;
     if (x >= nx) return;
     const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
     uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
-    const int row_step = gridDim.y * blockDim.y;
-    for (int ro = blockIdx.y * blockDim.y + threadIdx.y; ro < a.Ho; ro += row_step) {
+    const int row_step = a.row_step;
+    for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += row_step) {
         const uint32_t *rowp = in + (int64_t)(ro * 2) * a.W + (int64_t)x * (OPL * 2);
         uint32_t *op = out + (int64_t)ro * a.Wo + (int64_t)x * OPL;
         if (VAR == 1) {
@@ -331,12 +347,13 @@ __global__ void __launch_bounds__(256) k_dec2v(KArgs a)
 template <int ROUND, int FMT>
 __global__ void __launch_bounds__(256) k_generic(KArgs a)
 {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    pin_args(a);
+    const int co = blockIdx.x * a.bdx + threadIdx.x;
     if (co >= a.Wo) return;
     const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
     uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
-    const int row_step = gridDim.y * blockDim.y;
-    for (int ro = blockIdx.y * blockDim.y + threadIdx.y; ro < a.Ho; ro += row_step) {
+    const int row_step = a.row_step;
+    for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += row_step) {
         const int64_t y_idx = (int64_t)(ro * a.f) * a.W + co * a.f;
         int64_t c_idx;
         if (!a.s_first) {
@@ -574,6 +591,7 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
     unsigned gx = (unsigned)((lanes_x + bx - 1) / bx);
     unsigned gy = (unsigned)((rows + by - 1) / by);
     if (gy > 65535u) gy = 65535u;                     // kernels stride over rows
+    a.bdx = bx; a.bdy = by; a.row_step = (int32_t)gy * by;
     for (int f0 = 0; f0 < nframes; f0 += 65535) {     // grid z limit
         const int nz = (nframes - f0 < 65535) ? nframes - f0 : 65535;
         KArgs b = a;

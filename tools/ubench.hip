@@ -129,6 +129,42 @@ __global__ void __launch_bounds__(1024) k_e7(KArgs a)
     st4<NTS>(a.out + (int64_t)ro * a.Wo + x * 4, o);
 }
 
+// E8: f=1 shape (x4 load -> 4 px -> x4 store), full 8192x8192 frame, out buffer = another input-sized buffer
+template <bool NTL, bool NTS, int MODE>   // MODE 0 = copy, 1 = full 4:4:4 pipeline, 2 = 4:2:2 (chroma shared by pairs)
+__global__ void __launch_bounds__(256) k_e8(KArgs a)
+{
+    const int x4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    const int64_t base = (int64_t)row * a.W + 4 * x4;
+    const u32x4 p = ld4<NTL>(a.in + base);
+    u32x4 o;
+    if (MODE == 0) o = p;
+    else if (MODE == 1) { o.x = pix<true>(p.x, a); o.y = pix<true>(p.y, a); o.z = pix<true>(p.z, a); o.w = pix<true>(p.w, a); }
+    else {
+        const ChromaTerm t0 = chroma_term<R_FLOOR, F_ARGB>(p.x, a.mcb, a.mcr), t1 = chroma_term<R_FLOOR, F_ARGB>(p.z, a.mcb, a.mcr);
+        o.x = finish<F_ARGB>(p.x, a.my, t0); o.y = finish<F_ARGB>(p.y, a.my, t0);
+        o.z = finish<F_ARGB>(p.z, a.my, t1); o.w = finish<F_ARGB>(p.w, a.my, t1);
+    }
+    st4<NTS>(a.out + base, o);
+}
+
+// E9: f=1, K x4-groups per lane spaced by the block width (more bytes in flight per wave)
+template <int K, bool NT>
+__global__ void __launch_bounds__(256) k_e9(KArgs a)
+{
+    const int x0 = blockIdx.x * (256 * K) + threadIdx.x;
+    const int row = blockIdx.y;
+    const int64_t base = (int64_t)row * a.W;
+    u32x4 p[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) p[k] = ld4<NT>(a.in + base + 4 * (x0 + k * 256));
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        u32x4 o = {pix<true>(p[k].x, a), pix<true>(p[k].y, a), pix<true>(p[k].z, a), pix<true>(p[k].w, a)};
+        st4<NT>(a.out + base + 4 * (x0 + k * 256), o);
+    }
+}
+
 struct Bench {
     int W = 8192, H = 8192, Wo = 4096, Ho = 4096;
     int nring = 6, iters = 60;
@@ -146,7 +182,7 @@ struct Bench {
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         memset(&base, 0, sizeof base);
         base.W = W; base.H = H; base.Wo = Wo; base.Ho = Ho; base.my = base.mcb = base.mcr = 0xFF;
-        base.f = 2; base.in_frame_px = (int64_t)W * H; base.out_frame_px = (int64_t)Wo * Ho;
+        base.f = 2; base.bdx = 256; base.bdy = 1; base.row_step = 8192; base.in_frame_px = (int64_t)W * H; base.out_frame_px = (int64_t)Wo * Ho;
         CK(hipDeviceSynchronize());
     }
     template <class F> void run(const char *name, F launch, double bytes = 201326592.0)
@@ -229,5 +265,21 @@ int main()
 
     B.run("shipped k_dec K4 nt     grid 4x4096", L((k_dec<R_FLOOR, F_ARGB, 2, 1, false, 4, true>), dim3(4, 4096), dim3(256)));
     B.run("shipped k_dec2v var2 nt grid 4x4096", L((k_dec2v<R_FLOOR, F_ARGB, 2, true>), dim3(4, 4096), dim3(256)));
+
+    // ---- f = 1 shape: is the 4-px-per-lane pipeline VALU-limited? (out = next ring input buffer)
+    auto f1args = [&](int i) { KArgs a = B.base; a.in = B.in[i]; a.out = B.in[(i + 1) % B.nring]; return a; };
+    B.run("E8 f1 copy nt          grid 8x8192", [&](int i) { hipLaunchKernelGGL((k_e8<true, true, 0>), dim3(8, 8192), dim3(256), 0, 0, f1args(i)); }, 536870912.0);
+    B.run("E8 f1 4:4:4 nt         grid 8x8192", [&](int i) { hipLaunchKernelGGL((k_e8<true, true, 1>), dim3(8, 8192), dim3(256), 0, 0, f1args(i)); }, 536870912.0);
+    B.run("E8 f1 4:2:2 nt         grid 8x8192", [&](int i) { hipLaunchKernelGGL((k_e8<true, true, 2>), dim3(8, 8192), dim3(256), 0, 0, f1args(i)); }, 536870912.0);
+    B.run("E8 f1 4:4:4 cached     grid 8x8192", [&](int i) { hipLaunchKernelGGL((k_e8<false, false, 1>), dim3(8, 8192), dim3(256), 0, 0, f1args(i)); }, 536870912.0);
+
+    B.run("E9 f1 K2 4:4:4 nt      grid 4x8192", [&](int i) { hipLaunchKernelGGL((k_e9<2, true>), dim3(4, 8192), dim3(256), 0, 0, f1args(i)); }, 536870912.0);
+    B.run("E9 f1 K4 4:4:4 nt      grid 2x8192", [&](int i) { hipLaunchKernelGGL((k_e9<4, true>), dim3(2, 8192), dim3(256), 0, 0, f1args(i)); }, 536870912.0);
+    {
+        KArgs proto = B.base; proto.H = 8192; proto.Ho = 8192; proto.Wo = 8192; proto.f = 1;
+        auto sargs = [&](int i) { KArgs a = proto; a.in = B.in[i]; a.out = B.in[(i + 1) % B.nring]; return a; };
+        B.run("shipped k_f1x4 444 nt  grid 8x8192", [&](int i) { hipLaunchKernelGGL((k_f1x4<R_FLOOR, F_ARGB, 1, 1, true>), dim3(8, 8192), dim3(256), 0, 0, sargs(i)); }, 536870912.0);
+        B.run("shipped k_f1x4 420 nt  grid 8x8192", [&](int i) { hipLaunchKernelGGL((k_f1x4<R_FLOOR, F_ARGB, 2, 2, true>), dim3(8, 8192), dim3(256), 0, 0, sargs(i)); }, 536870912.0);
+    }
     return 0;
 }
