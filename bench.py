@@ -66,11 +66,30 @@ def cpu_baseline(W, H, a, b, bits, f, budget_s=10.0):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 64:
             break
-    return {
+    res = {
         "value": round(n * W * H / el / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
         "sample": f"{n} full {W}x{H} frames through oracle/csic_oracle.c orc_process_stream "
                   f"(scalar C -O2, streaming state machines) in {el:.1f} s; host has {os.cpu_count()} logical cores",
     }
+    # BASELINE.md "CPU baseline B": the same restatement (closed form) row-parallel on the cores this
+    # process may use; reported beside the single-thread number, never instead of it.
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 256))
+    fmt = orc.lib().orc_process_closed_mt
+    fmt(C.byref(cp), pin, pout, ncores)
+    m, t0 = 0, time.perf_counter()
+    while True:
+        fmt(C.byref(cp), pin, pout, ncores)
+        m += 1
+        el2 = time.perf_counter() - t0
+        if el2 >= min(budget_s, 5.0) or m >= 256:
+            break
+    res["all_cores"] = {"value": round(m * W * H / el2 / 1e6, 1), "unit": "Mpixels/s", "cores": ncores,
+                        "sample": f"{m} frames, orc_process_closed_mt on {ncores} threads in {el2:.1f} s"}
+    return res
 
 
 def main():
@@ -89,6 +108,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1; gloo only to rehearse the N>1 path on a 1-GPU box "
                          "(ranks then share GPU local_rank %% device_count)")
+    ap.add_argument("--per-frame-graph", action="store_true",
+                    help="multi-frame configs (cfg5): replay a hipGraph of per-frame launches (what BASELINE.json's "
+                         "cfg 5 literally names) instead of the single batched launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = ap.parse_args()
@@ -130,7 +152,7 @@ def main():
     if args.variant >= 0:
         plan.tune(N.TUNE_VARIANT, args.variant)
     in_px, out_px = W * sH, plan.out_width * plan.out_height
-    alg_bytes = plan.algorithmic_bytes * fps                      # per launch
+    alg_bytes = plan.algorithmic_bytes * (1 if args.per_frame_graph else fps)   # per launch
 
     # ---- ring of distinct frames, generated on the device ---------------------------------------
     step_in_bytes = in_px * 4 * fps
@@ -145,12 +167,35 @@ def main():
     in_ptrs = [C.c_void_p(t.data_ptr()) for t in ins]
     out_ptrs = [C.c_void_p(t.data_ptr()) for t in outs]
     ph = plan._h
+    launches_per_step = 1
     if fps == 1:
         def step(i):
             return lib.csic_process_device(ph, in_ptrs[i % nring], out_ptrs[i % nring], sh)
-    else:
+    elif not args.per_frame_graph:
         def step(i):
             return lib.csic_process_batch_device(ph, in_ptrs[i % nring], out_ptrs[i % nring], fps, sh)
+    else:
+        # one captured graph per ring slot: fps per-frame launches of csic_process_device
+        launches_per_step = fps
+        graphs = []
+        cap = torch.cuda.Stream(dev)
+        cap.wait_stream(stream)
+        with torch.cuda.stream(cap):
+            csh = C.c_void_p(cap.cuda_stream)
+            N.check(lib.csic_process_device(ph, in_ptrs[0], out_ptrs[0], csh))   # warm-up outside capture
+        stream.wait_stream(cap)
+        for k in range(nring):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                gsh = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                for j in range(fps):
+                    N.check(lib.csic_process_device(ph, C.c_void_p(ins[k].data_ptr() + 4 * j * in_px),
+                                                    C.c_void_p(outs[k].data_ptr() + 4 * j * out_px), gsh))
+            graphs.append(g)
+
+        def step(i):
+            graphs[i % nring].replay()
+            return 0
 
     def barrier():
         if world > 1:
@@ -191,7 +236,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms_avg = ev0.elapsed_time(ev1) / K
+    kern_ms_avg = ev0.elapsed_time(ev1) / K / launches_per_step
 
     # ---- diagnostic (untimed): an event pair around each of a few launches ----------------------
     npair = min(K, 50)
@@ -231,6 +276,7 @@ def main():
                 "stripe_rows_per_gpu": sH, "global_rows": gH, "ring_frames": nring, "prewarm_ms": args.prewarm_ms,
                 "parallelism": f"row-stripe x{world}, no collective",
                 "kernel": plan.kernel_name,
+                "launch": ("hipGraph of %d per-frame launches" % fps) if launches_per_step > 1 else "one launch per step",
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

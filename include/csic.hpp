@@ -1,0 +1,133 @@
+// csic.hpp -- header-only C++17 host layer over the C ABI of csic.h, keeping the reference's generator
+// names and argument lists (Scala originals under /root/reference/src/main/scala/jpeg/):
+//   csic::ImageProcessorParams  <- case class ImageProcessorParams           ImageProcessor.scala:15-29
+//   csic::ProcessingStep        <- object ProcessingStep extends ChiselEnum   ImageCompressorTop.scala:7-9
+//   csic::ImageCompressorTop    <- class ImageCompressorTop(11 parameters)    ImageCompressorTop.scala:11-25
+//   csic::ImageProcessor        <- class ImageProcessor(p)                    ImageProcessor.scala:31-63
+// Every require() of the reference surfaces as csic::IllegalArgumentException thrown from the
+// constructor, device failures as csic::RuntimeError.  No compute happens on the host.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "csic.h"
+
+namespace csic {
+
+struct IllegalArgumentException : std::invalid_argument {
+    int status;
+    IllegalArgumentException(int st, const std::string &m) : std::invalid_argument("requirement failed: " + m), status(st) {}
+};
+
+struct RuntimeError : std::runtime_error {
+    int status;
+    RuntimeError(int st, const std::string &m) : std::runtime_error(m), status(st) {}
+};
+
+inline int check(int status)
+{
+    if (status >= 0) return status;
+    std::string msg = csic_last_error();
+    if (msg.empty()) msg = csic_strerror(status);
+    if (status <= CSIC_EINVAL_NULL && status >= CSIC_EINVAL_SIZE) throw IllegalArgumentException(status, msg);
+    throw RuntimeError(status, msg);
+}
+
+enum class ProcessingStep : int32_t { NoOp = 0, SpatialSampling = 1, ColorQuantization = 2, ChromaSubsampling = 3 };
+enum class Rounding : int32_t { FLOOR_HW = CSIC_ROUND_FLOOR_HW, TRUNC_SW = CSIC_ROUND_TRUNC_SW };
+enum class PixelFormat : int32_t { ARGB8888 = CSIC_FMT_ARGB8888, YCBCR888X = CSIC_FMT_YCBCR888X };
+
+struct ImageProcessorParams {
+    int width, height, factor, chromaParamA, chromaParamB;
+    ImageProcessorParams(int width_, int height_, int factor_, int chromaParamA_, int chromaParamB_)
+        : width(width_), height(height_), factor(factor_), chromaParamA(chromaParamA_), chromaParamB(chromaParamB_)
+    {
+        csic_params p = c_params();
+        check(csic_validate(&p));      // the five require()s of ImageProcessor.scala:22-28
+    }
+    csic_params c_params(Rounding r = Rounding::FLOOR_HW, PixelFormat f = PixelFormat::ARGB8888) const
+    {
+        csic_params p;
+        csic_params_default(&p, width, height);
+        p.chroma_a = chromaParamA; p.chroma_b = chromaParamB; p.factor = factor;
+        p.rounding = (int32_t)r; p.out_format = (int32_t)f; p.strict_divisible = 1;
+        return p;
+    }
+};
+
+class ImageCompressorTop {
+public:
+    ImageCompressorTop(int width, int height, int chroma_param_a_config, int chroma_param_b_config,
+                       int yTargetQuantBitsConfig, int cbTargetQuantBitsConfig, int crTargetQuantBitsConfig,
+                       int downFactorConfig, ProcessingStep op1Type, ProcessingStep op2Type, ProcessingStep op3Type,
+                       Rounding rounding = Rounding::FLOOR_HW, int device = 0)
+        : device_(device)
+    {
+        csic_params_default(&params_, width, height);
+        params_.chroma_a = chroma_param_a_config; params_.chroma_b = chroma_param_b_config;
+        params_.y_bits = yTargetQuantBitsConfig; params_.cb_bits = cbTargetQuantBitsConfig; params_.cr_bits = crTargetQuantBitsConfig;
+        params_.factor = downFactorConfig;
+        params_.op[0] = (int32_t)op1Type; params_.op[1] = (int32_t)op2Type; params_.op[2] = (int32_t)op3Type;
+        params_.rounding = (int32_t)rounding;
+        check(csic_validate(&params_));                       // construction-time require()s
+        check(csic_out_dims(&params_, &out_w_, &out_h_));
+    }
+    ImageCompressorTop(const ImageCompressorTop &) = delete;
+    ImageCompressorTop &operator=(const ImageCompressorTop &) = delete;
+    virtual ~ImageCompressorTop()
+    {
+        csic_plan_destroy(plan_[0]);
+        csic_plan_destroy(plan_[1]);
+    }
+
+    int outWidth() const { return out_w_; }
+    int outHeight() const { return out_h_; }
+
+    // ARGB frame in -> reconstructed ARGB frame out (the DUT output put through YCbCrUtils.ycbcr2rgb,
+    // ImageCompressorTopApp.scala:118)
+    std::vector<uint32_t> process(const std::vector<uint32_t> &argb) { return run(PixelFormat::ARGB8888, argb); }
+    // ARGB frame in -> io.out's PixelYCbCrBundle stream, packed Y | Cb << 8 | Cr << 16
+    std::vector<uint32_t> processYCbCr(const std::vector<uint32_t> &argb) { return run(PixelFormat::YCBCR888X, argb); }
+    // device-resident, asynchronous on `hip_stream`
+    void processDevice(const void *d_in, void *d_out, void *hip_stream, PixelFormat f = PixelFormat::ARGB8888)
+    {
+        check(csic_process_device(plan(f), d_in, d_out, hip_stream));
+    }
+    const char *kernelName(PixelFormat f = PixelFormat::ARGB8888) { return csic_plan_kernel_name(plan(f)); }
+
+private:
+    csic_plan *plan(PixelFormat f)
+    {
+        csic_plan *&pl = plan_[(int)f];
+        if (!pl) {
+            csic_params p = params_;
+            p.out_format = (int32_t)f;
+            check(csic_plan_create(&p, device_, &pl));
+        }
+        return pl;
+    }
+    std::vector<uint32_t> run(PixelFormat f, const std::vector<uint32_t> &argb)
+    {
+        std::vector<uint32_t> out((size_t)out_w_ * out_h_);
+        check(csic_process_host(plan(f), argb.data(), argb.size(), out.data(), out.size()));
+        return out;
+    }
+    csic_params params_{};
+    csic_plan *plan_[2] = {nullptr, nullptr};
+    int32_t out_w_ = 0, out_h_ = 0;
+    int device_;
+};
+
+class ImageProcessor : public ImageCompressorTop {
+public:
+    explicit ImageProcessor(const ImageProcessorParams &p, Rounding rounding = Rounding::FLOOR_HW, int device = 0)
+        : ImageCompressorTop(p.width, p.height, p.chromaParamA, p.chromaParamB, 8, 8, 8, p.factor,
+                             ProcessingStep::ChromaSubsampling, ProcessingStep::SpatialSampling,
+                             ProcessingStep::ColorQuantization, rounding, device) {}
+};
+
+} // namespace csic

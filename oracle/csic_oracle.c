@@ -12,6 +12,7 @@
  */
 #include "csic_oracle.h"
 
+#include <pthread.h>
 #include <string.h>
 
 /* ------------------------------------------------------------------------- */
@@ -262,6 +263,38 @@ long orc_process_closed(const orc_params *p, const uint32_t *in, uint32_t *out)
     if (orc_validate(p) != 0) return -1;
     int32_t wo, ho; orc_out_dims(p, &wo, &ho);
     return orc_process_closed_rows(p, in, out, 0, ho);
+}
+
+/* Row-parallel closed form on `nthreads` POSIX threads (output rows are independent): the
+ * "all host cores" CPU baseline of BASELINE.md section 2.  Same results as orc_process_closed. */
+typedef struct { const orc_params *p; const uint32_t *in; uint32_t *out; int32_t ro0, ro1; long n; } mt_job;
+
+static void *mt_worker(void *arg)
+{
+    mt_job *j = (mt_job *)arg;
+    j->n = orc_process_closed_rows(j->p, j->in, j->out, j->ro0, j->ro1);
+    return NULL;
+}
+
+long orc_process_closed_mt(const orc_params *p, const uint32_t *in, uint32_t *out, int nthreads)
+{
+    if (orc_validate(p) != 0 || nthreads < 1) return -1;
+    if (nthreads > 1024) nthreads = 1024;
+    int32_t wo, ho; orc_out_dims(p, &wo, &ho);
+    pthread_t tid[1024];
+    mt_job job[1024];
+    int started = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        job[t].p = p; job[t].in = in; job[t].out = out; job[t].n = 0;
+        job[t].ro0 = (int32_t)((long)ho * t / nthreads);
+        job[t].ro1 = (int32_t)((long)ho * (t + 1) / nthreads);
+        if (pthread_create(&tid[t], NULL, mt_worker, &job[t]) != 0) break;
+        ++started;
+    }
+    long n = 0;
+    for (int t = 0; t < started; ++t) { pthread_join(tid[t], NULL); n += job[t].n; }
+    for (int t = started; t < nthreads; ++t) { mt_worker(&job[t]); n += job[t].n; }   /* thread creation failed: run inline */
+    return n;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -77,6 +77,9 @@ long orc_process_closed(const orc_params *p, const uint32_t *in, uint32_t *out);
 long orc_process_closed_rows(const orc_params *p, const uint32_t *in, uint32_t *out,
                              int32_t ro0, int32_t ro1);
 
+/* Closed form, output rows split over `nthreads` POSIX threads (CPU baseline on all host cores). */
+long orc_process_closed_mt(const orc_params *p, const uint32_t *in, uint32_t *out, int nthreads);
+
 /* ---- per-stage helpers on YCbCr streams (used by the KAT tests) ----------- */
 /* Chroma sample-and-hold on a stream of n (Y,Cb,Cr) triples, module width/height
  * W,H: ChromaSubsampler.scala:37-65 == ChromaSubsamplerImageSpec.scala:45-78. */

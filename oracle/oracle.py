@@ -87,6 +87,8 @@ def lib() -> C.CDLL:
         for fn in (L.orc_process_stream, L.orc_process_closed):
             fn.argtypes = [C.POINTER(_Params), u32p, u32p]
             fn.restype = C.c_long
+        L.orc_process_closed_mt.argtypes = [C.POINTER(_Params), u32p, u32p, C.c_int]
+        L.orc_process_closed_mt.restype = C.c_long
         L.orc_process_closed_rows.argtypes = [C.POINTER(_Params), u32p, u32p, C.c_int32, C.c_int32]
         L.orc_process_closed_rows.restype = C.c_long
         L.orc_rgb2ycbcr.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] * 3
@@ -153,6 +155,17 @@ def process(p: OracleParams, argb: np.ndarray, form: str = "stream") -> np.ndarr
     n = fn(C.byref(p.c()), _u32(a), _u32(out))
     if n != wo * ho:
         raise RuntimeError(f"oracle emitted {n} pixels, expected {wo * ho}")
+    return out.reshape(ho, wo)
+
+
+def process_mt(p: OracleParams, argb: np.ndarray, nthreads: int) -> np.ndarray:
+    """Row-parallel closed form (POSIX threads); must equal process(p, argb, "closed")."""
+    a = np.ascontiguousarray(argb, dtype=np.uint32).reshape(-1)
+    wo, ho = out_dims(p)
+    out = np.empty(wo * ho, dtype=np.uint32)
+    n = lib().orc_process_closed_mt(C.byref(p.c()), _u32(a), _u32(out), nthreads)
+    if n != wo * ho:
+        raise RuntimeError("oracle mt failure")
     return out.reshape(ho, wo)
 
 

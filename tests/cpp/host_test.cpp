@@ -1,0 +1,93 @@
+// host_test.cpp -- exercises include/csic.hpp.  `host_test cpu` checks the construction-time
+// require()s (no GPU needed); `host_test gpu` also pushes the reference's known-answer vectors through
+// the HIP path (RGB2YCbCrTester.scala:12-18, ColorQuantizerSpec.scala:43-61, SpatialDownsamplerSpec.scala:26).
+#include <cstdio>
+#include <cstring>
+
+#include "csic.hpp"
+
+using namespace csic;
+using PS = ProcessingStep;
+
+static int fails = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); ++fails; } } while (0)
+
+template <class F> static int iae_status(F f)
+{
+    try { f(); } catch (const IllegalArgumentException &e) { return e.status; } catch (...) { return 1; }
+    return 0;
+}
+
+static void cpu_checks()
+{
+    EXPECT(iae_status([] { ImageProcessorParams(16, 16, 2, 2, 0); }) == 0);
+    EXPECT(iae_status([] { ImageProcessorParams(0, 16, 1, 4, 4); }) == CSIC_EINVAL_DIMS);
+    EXPECT(iae_status([] { ImageProcessorParams(16, 16, 3, 4, 4); }) == CSIC_EINVAL_FACTOR);       // SpatialDownsamplerSpec.scala:147-151
+    EXPECT(iae_status([] { ImageProcessorParams(15, 16, 2, 4, 4); }) == CSIC_EINVAL_NOT_DIVISIBLE); // ImageProcessor.scala:25
+    EXPECT(iae_status([] { ImageProcessorParams(16, 16, 1, 3, 3); }) == CSIC_EINVAL_CHROMA_A);
+    EXPECT(iae_status([] { ImageProcessorParams(16, 16, 1, 2, 1); }) == CSIC_EINVAL_CHROMA_B);
+    EXPECT(iae_status([] { ImageCompressorTop(4, 4, 4, 4, 8, 8, 8, 2, PS::SpatialSampling, PS::SpatialSampling, PS::ChromaSubsampling); }) == CSIC_EINVAL_OP_PERMUTATION);
+    EXPECT(iae_status([] { ImageCompressorTop(4, 4, 4, 4, 9, 8, 8, 2, PS::SpatialSampling, PS::ColorQuantization, PS::ChromaSubsampling); }) == CSIC_EINVAL_BITS);
+    ImageCompressorTop t(5, 3, 4, 4, 8, 8, 8, 2, PS::SpatialSampling, PS::ColorQuantization, PS::ChromaSubsampling);
+    EXPECT(t.outWidth() == 3 && t.outHeight() == 2);                                              // SpatialDownsamplerSpec.scala:120-122
+    try { ImageProcessorParams(16, 16, 3, 4, 4); } catch (const IllegalArgumentException &e) {
+        EXPECT(std::strstr(e.what(), "requirement failed: factor must be 1, 2, 4, or 8") != nullptr);
+    }
+}
+
+static uint32_t argb(int r, int g, int b) { return 0xFF000000u | (r << 16) | (g << 8) | b; }
+static uint32_t ycc(int y, int cb, int cr) { return (uint32_t)y | (cb << 8) | (cr << 16); }
+
+static void gpu_checks()
+{
+    // 5 primaries, FLOOR_HW (what the RTL is checked against) and TRUNC_SW
+    const std::vector<uint32_t> prim = {argb(0, 0, 0), argb(255, 255, 255), argb(255, 0, 0), argb(0, 255, 0), argb(0, 0, 255)};
+    {
+        ImageCompressorTop t(5, 1, 4, 4, 8, 8, 8, 1, PS::ChromaSubsampling, PS::SpatialSampling, PS::ColorQuantization);
+        const auto o = t.processYCbCr(prim);
+        const uint32_t want[5] = {ycc(0, 128, 128), ycc(255, 128, 128), ycc(77, 85, 255), ycc(149, 43, 21), ycc(29, 255, 107)};
+        for (int i = 0; i < 5; ++i) EXPECT(o[i] == want[i]);
+        const auto rgb = t.process(prim);                          // inverse of the FLOOR results
+        const uint32_t wrgb[5] = {argb(0, 0, 0), argb(255, 255, 255), argb(255, 3, 3), argb(2, 255, 2), argb(0, 1, 255)};
+        for (int i = 0; i < 5; ++i) EXPECT(rgb[i] == wrgb[i]);
+    }
+    {
+        ImageCompressorTop t(5, 1, 4, 4, 8, 8, 8, 1, PS::ChromaSubsampling, PS::SpatialSampling, PS::ColorQuantization, Rounding::TRUNC_SW);
+        const auto o = t.processYCbCr(prim);
+        const uint32_t want[5] = {ycc(0, 128, 128), ycc(255, 128, 128), ycc(77, 86, 255), ycc(149, 44, 22), ycc(29, 255, 108)};
+        for (int i = 0; i < 5; ++i) EXPECT(o[i] == want[i]);
+    }
+    // decimation KAT: 4x4 grey ramp, f = 2 -> stream indices {0, 2, 8, 10}
+    {
+        std::vector<uint32_t> ramp(16);
+        for (int i = 0; i < 16; ++i) ramp[i] = argb(i, i, i);
+        ImageProcessor ip(ImageProcessorParams(4, 4, 2, 4, 4));
+        const auto o = ip.processYCbCr(ramp);
+        const int want[4] = {0, 2, 8, 10};
+        EXPECT(o.size() == 4);
+        for (int i = 0; i < 4; ++i) EXPECT((o[i] & 0xFF) == (uint32_t)want[i] && ((o[i] >> 8) & 0xFF) == 128);
+    }
+    // quantiser KAT Y3Cb3Cr2 on a grey pixel: (235,235,235) -> Y 235 & 0xE0 = 224, Cb 128 & 0xE0 = 128, Cr 128 & 0xC0 = 128
+    {
+        ImageCompressorTop t(1, 1, 4, 4, 3, 3, 2, 1, PS::ColorQuantization, PS::SpatialSampling, PS::ChromaSubsampling);
+        const auto o = t.processYCbCr({argb(235, 235, 235)});
+        EXPECT(o[0] == ycc(224, 128, 128));
+    }
+    // wrong buffer size is an IllegalArgumentException, bad device a RuntimeError
+    {
+        ImageCompressorTop t(4, 4, 4, 4, 8, 8, 8, 1, PS::ChromaSubsampling, PS::SpatialSampling, PS::ColorQuantization);
+        EXPECT(iae_status([&] { t.process(std::vector<uint32_t>(15)); }) == CSIC_EINVAL_SIZE);
+        bool rt = false;
+        try { ImageCompressorTop bad(4, 4, 4, 4, 8, 8, 8, 1, PS::ChromaSubsampling, PS::SpatialSampling, PS::ColorQuantization, Rounding::FLOOR_HW, 99); bad.process(std::vector<uint32_t>(16)); }
+        catch (const RuntimeError &e) { rt = e.status == CSIC_ENODEVICE; }
+        EXPECT(rt);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    cpu_checks();
+    if (argc > 1 && std::strcmp(argv[1], "gpu") == 0) gpu_checks();
+    std::printf(fails ? "%d check(s) failed\n" : "all checks passed\n", fails);
+    return fails ? 1 : 0;
+}

@@ -1,0 +1,37 @@
+"""Builds tests/cpp/host_test.cpp (g++, against include/csic.hpp + libcsic_hip.so) and runs it:
+the C++ host layer must throw on every reference require() without a GPU, and reproduce the
+reference's known-answer vectors on one."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+PKG = os.path.join(ROOT, "chroma-subsampling-image-compressor_amd")
+EXE = os.path.join(ROOT, "tests", "cpp", "host_test")
+
+
+def _build():
+    src = os.path.join(ROOT, "tests", "cpp", "host_test.cpp")
+    lib = os.path.join(PKG, "libcsic_hip.so")
+    assert os.path.exists(lib), "build libcsic_hip.so first (python -c 'import __graft_entry__ as g; g.build()')"
+    deps = [src, os.path.join(ROOT, "include", "csic.hpp"), os.path.join(ROOT, "include", "csic.h"), lib]
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), src,
+                               "-L" + PKG, "-lcsic_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib", "-o", EXE])
+    return EXE
+
+
+def _run(mode):
+    r = subprocess.run([_build(), mode], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+
+
+def test_cpp_host_layer_requires():
+    _run("cpu")
+
+
+@pytest.mark.gpu
+def test_cpp_host_layer_kats_on_gpu():
+    _run("gpu")

@@ -368,3 +368,30 @@ def test_app_default_order_sf8(csic, oracle, input_images):
     top = csic.ImageCompressorTop(128, 128, 4, 4, 8, 8, 8, 8, 1, 2, 3)
     assert np.array_equal(top.process(argb), want)
     top.close()
+
+
+def test_frames_beyond_4gib_offsets(csic, oracle):
+    """Maximum-size addressing: a 32768 x 40960 frame (1.34 Gpixel, 5.4 GB; byte offsets pass 2^32 and
+    pixel indices approach the 2^31 limit csic_validate enforces).  Checked through the stripe property:
+    the bottom and top aligned stripes of the big frame must equal the same rows processed as small
+    independent frames, which in turn are checked against the oracle."""
+    import torch
+    W, H = 32768, 40960
+    lib = csic._native.lib()
+    sh = C.c_void_p(torch.cuda.current_stream(0).cuda_stream)
+    d_in = torch.empty(W * H, dtype=torch.int32, device="cuda:0")
+    csic._native.check(lib.csic_synth_frame_device(C.c_void_p(d_in.data_ptr()), W * H, 0, 20250629, sh))
+    rows = 64
+    for (a, b, bits, f) in [(2, 0, (3, 3, 2), 1), (2, 0, (8, 8, 8), 2), (1, 1, (6, 5, 5), 8)]:
+        with _plan(csic, W, H, a, b, bits, f) as big, _plan(csic, W, rows, a, b, bits, f) as small:
+            d_out = big.process_device(d_in)
+            for r0 in (0, H - rows):
+                part = small.process_device(d_in[r0 * W:(r0 + rows) * W].contiguous())
+                torch.cuda.synchronize()
+                assert torch.equal(part, d_out[r0 // f:(r0 + rows) // f]), (a, b, f, r0)
+                host = d_in[r0 * W:(r0 + rows) * W].cpu().numpy().view(np.uint32)
+                want = oracle.process(_oparams(oracle, W, rows, a, b, bits, f), host, form="closed")
+                assert np.array_equal(part.cpu().numpy().view(np.uint32), want)
+            del d_out
+    with pytest.raises(csic.IllegalArgumentException):
+        _plan(csic, 65536, 32768)                                        # 2^31 pixels: rejected

@@ -73,3 +73,13 @@ def test_synth_frame_properties(oracle):
     # fmix32 known values: fmix32(0 + salt) etc. are self-consistent; pin the first few outputs
     assert oracle.synth_frame(4, 0, seed=0).tolist() == [0xFF000000 | (v & 0xFFFFFF) for v in
                                                         (0x0, 0x514E28B7, 0x30F4C306, 0x85F0B427)]
+
+
+def test_multithreaded_closed_form_matches(oracle):
+    rng = np.random.default_rng(21)
+    for (W, H, a, b, f, op) in [(96, 70, 2, 0, 1, (3, 1, 2)), (128, 64, 2, 0, 2, (3, 1, 2)), (64, 33, 1, 0, 4, (1, 3, 2))]:
+        argb = rng.integers(0, 1 << 32, W * H, dtype=np.uint32)
+        p = oracle.OracleParams(width=W, height=H, chroma_a=a, chroma_b=b, y_bits=3, cb_bits=3, cr_bits=2, factor=f, op=op)
+        want = oracle.process(p, argb, "stream")
+        for nt in (1, 3, 8, 64):
+            assert np.array_equal(oracle.process_mt(p, argb, nt), want)
