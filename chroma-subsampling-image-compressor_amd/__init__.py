@@ -10,12 +10,13 @@ from ._native import CsicRuntimeError, IllegalArgumentException
 from .params import ImageProcessorParams, PixelFormat, ProcessingStep, Rounding, make_c_params
 from .compressor import ImageCompressorTop, ImageProcessor, Plan
 from .model import Image, ImageProcessorModel
+from .pipeline import FramePipeline
 from .app import ImageCompressionApp
 from .distributed import Stripe, StripedImageCompressorTop, stripe_for_rank
-from . import app, compressor, distributed, model, params
+from . import app, compressor, distributed, model, params, pipeline
 
 __all__ = [
     "CsicRuntimeError", "IllegalArgumentException", "ImageProcessorParams", "PixelFormat", "ProcessingStep",
     "Rounding", "make_c_params", "ImageCompressorTop", "ImageProcessor", "Plan", "Image", "ImageProcessorModel",
-    "ImageCompressionApp", "Stripe", "StripedImageCompressorTop", "stripe_for_rank",
+    "ImageCompressionApp", "FramePipeline", "Stripe", "StripedImageCompressorTop", "stripe_for_rank",
 ]

@@ -19,6 +19,7 @@ OP_NOOP, OP_SPATIAL, OP_QUANT, OP_CHROMA = 0, 1, 2, 3
 ROUND_FLOOR_HW, ROUND_TRUNC_SW = 0, 1
 FMT_ARGB8888, FMT_YCBCR888X = 0, 1
 TUNE_VARIANT, TUNE_FORCE_GENERIC, TUNE_NONTEMPORAL = 1, 2, 3
+PIPELINE_STAGED, PIPELINE_ZERO_COPY = 0, 1
 
 
 class IllegalArgumentException(ValueError):
@@ -72,6 +73,13 @@ PROTOTYPES = {
     "csic_process_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "csic_synth_frame_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]),
     "csic_checksum_device": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64), C.c_void_p]),
+    "csic_pipeline_create": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "csic_pipeline_destroy": (C.c_int, [C.c_void_p]),
+    "csic_pipeline_acquire_input": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32))]),
+    "csic_pipeline_submit": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "csic_pipeline_collect": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]),
+    "csic_pipeline_pending": (C.c_int, [C.c_void_p]),
+    "csic_pipeline_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
 }
 
 _lib = None

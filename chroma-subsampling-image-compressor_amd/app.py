@@ -52,6 +52,44 @@ class ImageCompressionApp:
         ImageProcessorModel.writeImage(Image(stream.reshape(finalH, finalW)), outputImagePath)
 
 
+    @staticmethod
+    def processImages(inputImagePaths, outputImagePaths, chromaParamA: int, chromaParamB: int,
+                      yTargetBits: int, cbTargetBits: int, crTargetBits: int, spatialFactorToUse: int,
+                      op1: ProcessingStep, op2: ProcessingStep, op3: ProcessingStep, *, device: int = 0,
+                      depth: int = 3) -> None:
+        """Many same-sized images through one plan and a FramePipeline: PNGs are decoded straight into
+        pinned staging, and H2D / kernel / D2H of neighbouring images overlap.  Output files are what
+        processImage would write for each input."""
+        from .pipeline import FramePipeline
+        first = ImageProcessorModel.readImage(inputImagePaths[0])
+        W, H, f = first.width, first.height, spatialFactorToUse
+        top = ImageCompressorTop(W, H, chromaParamA, chromaParamB, yTargetBits, cbTargetBits, crTargetBits,
+                                 f, op1, op2, op3, device=device)
+        finalW, finalH = W // f, H // f
+        todo = list(outputImagePaths)
+
+        def write(stream_frame, path):
+            stream = stream_frame.reshape(-1)[: finalW * finalH]
+            if stream.size < finalW * finalH:
+                stream = np.concatenate([stream, np.full(finalW * finalH - stream.size, 0xFFFF00FF, dtype=np.uint32)])
+            ImageProcessorModel.writeImage(Image(stream.reshape(finalH, finalW).copy()), path)
+
+        with FramePipeline(top.plan(), depth) as pipe:
+            done = 0
+            for k, path in enumerate(inputImagePaths):
+                img = first if k == 0 else ImageProcessorModel.readImage(path)
+                if (img.width, img.height) != (W, H):
+                    raise N.IllegalArgumentException(N.EINVAL_SIZE, f"requirement failed: {path} is {img.width}x{img.height}, "
+                                                     f"expected {W}x{H}")
+                if pipe.pending == depth:
+                    write(pipe.collect()[1], todo[done]); done += 1
+                np.copyto(pipe.acquire_input(), img.argb)
+                pipe.submit()
+            while pipe.pending:
+                write(pipe.collect()[1], todo[done]); done += 1
+        top.close()
+
+
 def _order_tag(step: ProcessingStep) -> str:
     # `${op.toString.split('.').last.take(2)}` on a ChiselEnum value "ProcessingStep(1=SpatialSampling)"
     # yields "Pr" for every step (ImageCompressorTopApp.scala:188).

@@ -604,6 +604,18 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
     return CSIC_OK;
 }
 
+// entry points for csic_pipeline.hip
+int launch_on_stream(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream)
+{
+    return launch(pl, d_in, d_out, nframes, stream);
+}
+int plan_device(const csic_plan *pl) { return pl->device; }
+void plan_sizes(const csic_plan *pl, size_t *in_px, size_t *out_px)
+{
+    *in_px = (size_t)pl->g.W * pl->g.H;
+    *out_px = (size_t)pl->g.Wo * pl->g.Ho;
+}
+
 } // namespace csic
 
 using namespace csic;

@@ -181,6 +181,36 @@ int  csic_synth_frame_device(void *d_dst, int64_t npix, int64_t first_index, uin
  * (pixel, index) pairs), for the full-size parity properties; synchronous. */
 int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *hip_stream);
 
+/* ---- host-frame pipeline (the step either side of the hot path) -----------------------------------
+ * Replaces the reference's per-image  readImage -> per-pixel poke ... peek -> writeImage  flow
+ * (ImageProcessorModel.scala:14-52, ImageCompressorTopApp.scala:39-41,76-144) for streams of frames that
+ * live in host memory: `depth` slots, each with pinned host input/output staging, device buffers and its
+ * own HIP stream, so that frame k+1's H2D copy, frame k's kernel and frame k-1's D2H copy overlap.
+ *
+ *   csic_pipeline_acquire_input : pointer to the next slot's pinned input buffer (width*height pixels);
+ *                                 decode/write the frame straight into it.  Fails with CSIC_EINVAL_SIZE
+ *                                 when every slot still holds an uncollected frame.
+ *   csic_pipeline_submit        : enqueue H2D + kernel + D2H for the acquired buffer (asynchronous).
+ *   csic_pipeline_collect       : wait for the OLDEST submitted frame; *host_out points at its pinned
+ *                                 output (out_width*out_height pixels), valid until that slot is submitted
+ *                                 again.  Frames complete in submission order; *ticket counts from 0.
+ * The plan must outlive the pipeline.  Not thread-safe (one producer/consumer thread). */
+typedef struct csic_pipeline csic_pipeline;
+int  csic_pipeline_create(csic_plan *plan, int32_t depth, csic_pipeline **out);
+int  csic_pipeline_destroy(csic_pipeline *pipeline);
+int  csic_pipeline_acquire_input(csic_pipeline *pipeline, uint32_t **host_in);
+int  csic_pipeline_submit(csic_pipeline *pipeline, int64_t *ticket);
+int  csic_pipeline_collect(csic_pipeline *pipeline, const uint32_t **host_out, int64_t *ticket);
+int  csic_pipeline_pending(const csic_pipeline *pipeline);
+/* CSIC_PIPELINE_ZERO_COPY (default): the kernel reads the pinned host input and writes the pinned host
+ *     output directly over PCIe: dead input rows (r % factor != 0) never cross the bus and both PCIe
+ *     directions are busy inside one launch (8192x8192 sf=2: 2.4 ms/frame vs 5.9 ms staged).
+ * CSIC_PIPELINE_STAGED: hipMemcpyAsync H2D -> kernel -> hipMemcpyAsync D2H through device buffers; keeps
+ *     the CUs free while the copy engines move the frame. */
+#define CSIC_PIPELINE_STAGED    0
+#define CSIC_PIPELINE_ZERO_COPY 1
+int  csic_pipeline_set_mode(csic_pipeline *pipeline, int32_t mode);
+
 #ifdef __cplusplus
 }
 #endif

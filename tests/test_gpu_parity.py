@@ -395,3 +395,49 @@ def test_frames_beyond_4gib_offsets(csic, oracle):
             del d_out
     with pytest.raises(csic.IllegalArgumentException):
         _plan(csic, 65536, 32768)                                        # 2^31 pixels: rejected
+
+
+# ---- host-frame pipeline (pinned staging, H2D || kernel || D2H) ---------------------------------------
+@pytest.mark.parametrize("zero_copy", [False, True])
+@pytest.mark.parametrize("depth", [1, 2, 4])
+def test_frame_pipeline_matches_oracle_in_order(csic, oracle, depth, zero_copy):
+    W, H, n = 640, 360, 9
+    frames = [oracle.synth_frame(W * H, k * W * H).reshape(H, W) for k in range(n)]
+    op = _oparams(oracle, W, H, 2, 0, (3, 3, 2), 2)
+    with _plan(csic, W, H, 2, 0, (3, 3, 2), 2) as pl, csic.FramePipeline(pl, depth, zero_copy=zero_copy) as pipe:
+        outs = list(pipe.run(frames))
+        assert len(outs) == n
+        for k in range(n):
+            assert np.array_equal(outs[k], oracle.process(op, frames[k])), k
+        # explicit protocol: tickets count up, slots cannot be over-acquired, views are pinned buffers
+        for k in range(depth):
+            buf = pipe.acquire_input()
+            assert buf.shape == (H, W) and buf.dtype == np.uint32
+            buf[...] = frames[k]
+            assert pipe.submit() == n + k
+        with pytest.raises(csic.IllegalArgumentException):
+            pipe.acquire_input()                                   # every slot holds an uncollected frame
+        for k in range(depth):
+            t, out = pipe.collect()
+            assert t == n + k and np.array_equal(out, oracle.process(op, frames[k]))
+        with pytest.raises(csic.IllegalArgumentException):
+            pipe.collect()                                         # nothing pending
+        with pytest.raises(csic.IllegalArgumentException):
+            pipe.submit()                                          # nothing acquired
+
+
+def test_app_process_images_batch(csic, oracle, tmp_path):
+    from PIL import Image as PILImage
+    W, H, n = 96, 64, 5
+    PS = csic.ProcessingStep
+    ins, outs, rgbs = [], [], []
+    for k in range(n):
+        rgb = oracle.argb_to_rgb(oracle.synth_frame(W * H, 1000 * k).reshape(H, W))
+        p = tmp_path / f"in{k}.png"
+        PILImage.fromarray(rgb, "RGB").save(p)
+        ins.append(str(p)); outs.append(str(tmp_path / "out" / f"o{k}.png")); rgbs.append(rgb)
+    csic.ImageCompressionApp.processImages(ins, outs, 2, 0, 3, 3, 2, 2, PS.ChromaSubsampling, PS.SpatialSampling,
+                                           PS.ColorQuantization, depth=2)
+    for k in range(n):
+        want = oracle.argb_to_rgb(oracle.process(_oparams(oracle, W, H, 2, 0, (3, 3, 2), 2), oracle.rgb_to_argb(rgbs[k])))
+        assert np.array_equal(load_png_rgb(outs[k]), want)

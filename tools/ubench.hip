@@ -165,6 +165,37 @@ __global__ void __launch_bounds__(256) k_e9(KArgs a)
     }
 }
 
+// ceilings: read-only (sum into one dword per wave so nothing is DCE'd), write-only
+__global__ void __launch_bounds__(256) k_read_nt(const uint32_t *in, uint32_t *sink, int64_t n4)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const u32x4 v = ld4<true>(in + 4 * i);
+    const uint32_t s = v.x ^ v.y ^ v.z ^ v.w;
+    if (s == 0x12345678u) sink[0] = s;             // practically never
+}
+__global__ void __launch_bounds__(256) k_write_nt(uint32_t *out, int64_t n4, uint32_t v)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const u32x4 o = {v, v + 1, v + 2, v + 3};
+    st4<true>(out + 4 * i, o);
+}
+// E10: shipped-shape dword kernel but reading CONTIGUOUS rows (row stride W instead of 2W): does skipping cost?
+template <int K>
+__global__ void __launch_bounds__(256) k_e10(KArgs a, int row_mul)
+{
+    const int co0 = blockIdx.x * (256 * K) + threadIdx.x;
+    const int ro = blockIdx.y;
+    const uint32_t *rp = a.in + (int64_t)(ro * row_mul) * a.W;
+    uint32_t *op = a.out + (int64_t)ro * a.Wo;
+    uint32_t px[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) px[k] = ld1<true>(rp + (co0 + k * 256) * 2);
+#pragma unroll
+    for (int k = 0; k < K; ++k) st1<true>(op + co0 + k * 256, pix<true>(px[k], a));
+}
+
 struct Bench {
     int W = 8192, H = 8192, Wo = 4096, Ho = 4096;
     int nring = 6, iters = 60;
@@ -281,5 +312,11 @@ int main()
         B.run("shipped k_f1x4 444 nt  grid 8x8192", [&](int i) { hipLaunchKernelGGL((k_f1x4<R_FLOOR, F_ARGB, 1, 1, true>), dim3(8, 8192), dim3(256), 0, 0, sargs(i)); }, 536870912.0);
         B.run("shipped k_f1x4 420 nt  grid 8x8192", [&](int i) { hipLaunchKernelGGL((k_f1x4<R_FLOOR, F_ARGB, 2, 2, true>), dim3(8, 8192), dim3(256), 0, 0, sargs(i)); }, 536870912.0);
     }
+
+    B.run("read-only nt 256MiB   65536 blk", [&](int i) { hipLaunchKernelGGL(k_read_nt, dim3(65536), dim3(256), 0, 0, (const uint32_t *)B.in[i], B.out[0], (int64_t)B.W * B.H / 4); }, 268435456.0);
+    B.run("write-only nt 256MiB  65536 blk", [&](int i) { hipLaunchKernelGGL(k_write_nt, dim3(65536), dim3(256), 0, 0, B.in[i], (int64_t)B.W * B.H / 4, (uint32_t)i); }, 268435456.0);
+    B.run("E10 K4 rows skipped (x2) grid 4x4096", [&](int i) { hipLaunchKernelGGL((k_e10<4>), dim3(4, 4096), dim3(256), 0, 0, B.args(i), 2); });
+    B.run("E10 K4 rows contiguous   grid 4x4096", [&](int i) { hipLaunchKernelGGL((k_e10<4>), dim3(4, 4096), dim3(256), 0, 0, B.args(i), 1); });
+    for (int i = 0; i < B.nring; ++i) hipLaunchKernelGGL(k_synth, dim3(8192), dim3(256), 0, 0, B.in[i], (int64_t)B.W * B.H, (int64_t)i * B.W * B.H, 20250629u * 0x9E3779B9u);
     return 0;
 }
