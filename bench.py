@@ -103,6 +103,7 @@ def main():
                          "cfg4 measures 33.9 us/step cold vs 32.5 us/step conditioned)")
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (CSIC_TUNE_VARIANT); -1 = library default")
+    ap.add_argument("--no-vector", action="store_true", help="CSIC_TUNE_NO_VECTOR: 4-byte-access kernels only (A/B)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--ring-mib", type=int, default=2048, help="input bytes rotated through (MiB), per GPU")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -151,6 +152,8 @@ def main():
     plan = csic.Plan(csic.make_c_params(W, sH, a, b, *bits, f, CSQ), dev_index)
     if args.variant >= 0:
         plan.tune(N.TUNE_VARIANT, args.variant)
+    if args.no_vector:
+        plan.tune(N.TUNE_NO_VECTOR, 1)
     in_px, out_px = W * sH, plan.out_width * plan.out_height
     alg_bytes = plan.algorithmic_bytes * (1 if args.per_frame_graph else fps)   # per launch
 

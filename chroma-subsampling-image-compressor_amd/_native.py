@@ -18,7 +18,7 @@ ENODEVICE, EHIP, ENOMEM = -20, -21, -22
 OP_NOOP, OP_SPATIAL, OP_QUANT, OP_CHROMA = 0, 1, 2, 3
 ROUND_FLOOR_HW, ROUND_TRUNC_SW = 0, 1
 FMT_ARGB8888, FMT_YCBCR888X = 0, 1
-TUNE_VARIANT, TUNE_FORCE_GENERIC, TUNE_NONTEMPORAL = 1, 2, 3
+TUNE_VARIANT, TUNE_FORCE_GENERIC, TUNE_NONTEMPORAL, TUNE_NO_VECTOR = 1, 2, 3, 4
 PIPELINE_STAGED, PIPELINE_ZERO_COPY = 0, 1
 
 

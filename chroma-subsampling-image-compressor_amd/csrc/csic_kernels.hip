@@ -181,13 +181,16 @@ __global__ void __launch_bounds__(256) k_f1x4(KArgs a)
     const int row_step = a.row_step;
     for (int row = blockIdx.y * a.bdy + threadIdx.y; row < a.H; row += row_step) {
         const int64_t base = (int64_t)row * a.W + 4 * x4;
+        // 4:x:0 odd row: no pixel is a sample point, the whole row replays the chroma latched at the last
+        // sample of the previous row (ChromaSubsampler.scala:52-65).  Its load is
+        // issued ahead of the 16-byte stream load so that the two latencies overlap.
+        const bool odd = (VV == 2) && (row & 1);
+        uint32_t cpx = 0;
+        if (odd) cpx = in[(int64_t)(row - 1) * a.W + a.last_sample_col];
         const u32x4 p = ld4<NT>(in + base);
         const uint32_t px[4] = {p.x, p.y, p.z, p.w};
         uint32_t o[4];
-        if (VV == 2 && (row & 1)) {
-            // 4:x:0 odd row: no pixel is a sample point, the whole row replays the chroma latched at
-            // the last sample of the previous row (ChromaSubsampler.scala:52-65)
-            const uint32_t cpx = in[(int64_t)(row - 1) * a.W + a.last_sample_col];
+        if (odd) {
             const ChromaTerm t = chroma_term<ROUND, FMT>(cpx, a.mcb, a.mcr);
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = finish<FMT>(px[i], a.my, t);
@@ -416,6 +419,7 @@ struct csic_plan {
     int device;
     int variant;
     int force_generic;
+    int no_vec;          // 1 = no 16-byte vector kernels (set per launch for pointers that are only 4-byte aligned)
     int no_nt;           // 1 = plain (cached) loads/stores instead of non-temporal ones
     // selection (recomputed by select())
     csic::Family fam;
@@ -468,6 +472,7 @@ static KernelFn pick_dec_f(int hold, bool srows)
 template <int ROUND, int FMT, bool NT>
 static KernelFn pick_dec(int f, int hold, bool srows)
 {
+    if (f == 1) return pick_dec_f<ROUND, FMT, 1, NT>(hold, srows);
     if (f == 2) return pick_dec_f<ROUND, FMT, 2, NT>(hold, srows);
     if (f == 4) return pick_dec_f<ROUND, FMT, 4, NT>(hold, srows);
     return pick_dec_f<ROUND, FMT, 8, NT>(hold, srows);
@@ -478,7 +483,7 @@ static KernelFn pick_dec(int f, int hold, bool srows)
 // coincide with groups of decimated rows (f | W) and the in-row hold is lane-aligned (h | Wo).
 static bool dec_fast_ok(const Geometry &g)
 {
-    const int hold = g.s_first ? g.h : (g.h > g.f ? g.h / g.f : 1);
+    const int hold = (g.s_first || g.f == 1) ? g.h : (g.h > g.f ? g.h / g.f : 1);
     const int lanes_x = (g.Wo + DEC_K - 1) / DEC_K;
     if (hold > 1 && lanes_x < 3) return false;            // block width < 4 lanes: quads would span rows
     if (!g.s_first) return true;
@@ -493,17 +498,22 @@ static void select_rf(csic_plan *pl)
     const char *fn = FMT == F_ARGB ? "argb" : "ycc";
     const bool nt = !pl->no_nt;
     const char *ntn = nt ? "nt" : "cached";
-    if (!pl->force_generic && g.f == 1 && g.W % 4 == 0) {
+    // f = 1: the 16-byte kernel wins for v = 1 (8192^2 4:4:4: 84.1 vs 88.0 us); for 4:x:0 the 4-byte k_dec<f1>
+    // with its per-row broadcast wins (86.2 vs 89-91 us), unless the frame is too narrow for it.
+    const bool f1x4_ok = !pl->force_generic && !pl->no_vec && g.f == 1 && g.W % 4 == 0;
+    if (f1x4_ok && (g.v == 1 || pl->variant == 3 || !dec_fast_ok(g))) {
         pl->fam = FAM_F1X4;
         pl->fn = nt ? pick_f1x4<ROUND, FMT, true>(g.h, g.v) : pick_f1x4<ROUND, FMT, false>(g.h, g.v);
         pl->units_per_row = g.W / 4;
         pl->k_per_lane = 1;
         snprintf(pl->name, sizeof pl->name, "k_f1x4<%s,%s,h%d,v%d,%s>", rn, fn, g.h, g.v, ntn);
-    } else if (!pl->force_generic && g.f > 1 && dec_fast_ok(g)) {
+    } else if (!pl->force_generic && dec_fast_ok(g)) {
         // in-row chroma hold distance in decimated lanes; srows = chroma rows follow the decimated stream
-        const bool srows = g.s_first != 0;
+        // (with f = 1 the decimated stream IS the image and both order classes coincide: any width, any
+        // 4-byte-aligned pointer, 4-byte accesses)
+        const bool srows = g.s_first != 0 || g.f == 1;
         const int hold = srows ? g.h : (g.h > g.f ? g.h / g.f : 1);
-        if (g.f == 2 && hold == 1 && !srows && g.W % 8 == 0 && (pl->variant == 1 || pl->variant == 2)) {
+        if (g.f == 2 && hold == 1 && !srows && !pl->no_vec && g.W % 8 == 0 && (pl->variant == 1 || pl->variant == 2)) {
             pl->fam = pl->variant == 1 ? FAM_DEC2V1 : FAM_DEC2V2;
             if (pl->variant == 1) pl->fn = nt ? (KernelFn)k_dec2v<ROUND, FMT, 1, true> : (KernelFn)k_dec2v<ROUND, FMT, 1, false>;
             else                  pl->fn = nt ? (KernelFn)k_dec2v<ROUND, FMT, 2, true> : (KernelFn)k_dec2v<ROUND, FMT, 2, false>;
@@ -517,7 +527,7 @@ static void select_rf(csic_plan *pl)
             pl->units_per_row = g.Wo;
             pl->k_per_lane = DEC_K;
             snprintf(pl->name, sizeof pl->name, "k_dec<%s,%s,f%d,hold%d,%s,K%d,%s>", rn, fn, g.f, hold,
-                     srows ? (g.v == 2 ? "s>c,v2" : "s>c") : "c>s", DEC_K, ntn);
+                     g.f == 1 ? (g.v == 2 ? "v2" : "v1") : srows ? (g.v == 2 ? "s>c,v2" : "s>c") : "c>s", DEC_K, ntn);
         }
     } else {
         pl->fam = FAM_GENERIC;
@@ -559,11 +569,11 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
     Family fam = pl->fam;
     KernelFn fn = pl->fn;
     int units = pl->units_per_row, kpl = pl->k_per_lane;
-    // The vector kernels need 16-byte aligned frame bases; otherwise take the generic kernel.
+    // The vector kernels need 16-byte aligned frame bases; otherwise take the 4-byte-access kernels.
     const bool vec = (fam == FAM_F1X4 || fam == FAM_DEC2V1 || fam == FAM_DEC2V2);
     if (vec && ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15u)) {
         csic_plan tmp = *pl;
-        tmp.force_generic = 1;
+        tmp.no_vec = 1;
         select(&tmp);
         fam = tmp.fam; fn = tmp.fn; units = tmp.units_per_row; kpl = tmp.k_per_lane;
     }
@@ -676,6 +686,7 @@ int csic_plan_tune(csic_plan *plan, int32_t knob, int32_t value)
     if (knob == CSIC_TUNE_VARIANT) plan->variant = value;
     else if (knob == CSIC_TUNE_FORCE_GENERIC) plan->force_generic = value ? 1 : 0;
     else if (knob == CSIC_TUNE_NONTEMPORAL) plan->no_nt = value ? 0 : 1;
+    else if (knob == CSIC_TUNE_NO_VECTOR) plan->no_vec = value ? 1 : 0;
     else return set_error(CSIC_EINVAL_SIZE, "unknown tuning knob %d", knob);
     select(plan);
     clear_error();

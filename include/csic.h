@@ -149,10 +149,12 @@ const char *csic_plan_kernel_name(const csic_plan *plan);
 /* Tuning knobs for A/B measurements; a knob the selected kernel does not have is ignored.
  *   CSIC_TUNE_VARIANT : kernel-family specific variant index (0 = default)
  *   CSIC_TUNE_FORCE_GENERIC : 1 = always use the one-thread-per-pixel generic kernel
- *   CSIC_TUNE_NONTEMPORAL   : 1 (default) = non-temporal loads/stores for the frame stream, 0 = cached */
+ *   CSIC_TUNE_NONTEMPORAL   : 1 (default) = non-temporal loads/stores for the frame stream, 0 = cached
+ *   CSIC_TUNE_NO_VECTOR     : 1 = never use the 16-byte-per-lane kernels */
 #define CSIC_TUNE_VARIANT        1
 #define CSIC_TUNE_FORCE_GENERIC  2
 #define CSIC_TUNE_NONTEMPORAL    3
+#define CSIC_TUNE_NO_VECTOR      4   /* 1 = 4-byte accesses only (what unaligned pointers get automatically) */
 int  csic_plan_tune(csic_plan *plan, int32_t knob, int32_t value);
 
 /* One frame, device-resident: d_in holds width*height input pixels, d_out receives

@@ -71,13 +71,17 @@ def test_random_shapes_vs_oracle(csic, oracle, seed):
             seen.add(pl.kernel_name.split("<")[0])
             got = pl.process_host(argb)
             assert np.array_equal(got, want), (pl.kernel_name, W, H, a, b, bits, f, op, rounding, fmt)
-            for variant in (1, 2):                      # 16-byte-load variants of the f=2 kernel
+            for variant in (1, 2, 3):                   # 16-byte-load variants (3 = k_f1x4 also for 4:x:0)
                 pl.tune(csic._native.TUNE_VARIANT, variant)
                 assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
             pl.tune(csic._native.TUNE_VARIANT, 0)
             pl.tune(csic._native.TUNE_NONTEMPORAL, 0)   # cached loads/stores instead of nt
             assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
+            pl.tune(csic._native.TUNE_NO_VECTOR, 1)     # 4-byte-access kernels only
+            seen.add(pl.kernel_name.split("<")[0])
+            assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
             pl.tune(csic._native.TUNE_FORCE_GENERIC, 1)
+            assert pl.kernel_name.startswith("k_generic")
             assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
     assert {"k_f1x4", "k_dec", "k_generic"} <= seen
 
@@ -128,7 +132,7 @@ def test_cfg2_128_422_q8(csic, oracle, input_images):
     argb = oracle.rgb_to_argb(input_images["in128"])
     want = oracle.process(_oparams(oracle, 128, 128, 2, 2, (3, 3, 2)), argb)
     with _plan(csic, 128, 128, 2, 2, (3, 3, 2)) as pl:
-        assert pl.kernel_name.startswith("k_f1x4")
+        assert pl.kernel_name.startswith("k_f1x4")           # 4:2:2 (v = 1): the 16-byte kernel
         assert np.array_equal(pl.process_host(argb), want)
 
 
@@ -441,3 +445,16 @@ def test_app_process_images_batch(csic, oracle, tmp_path):
     for k in range(n):
         want = oracle.argb_to_rgb(oracle.process(_oparams(oracle, W, H, 2, 0, (3, 3, 2), 2), oracle.rgb_to_argb(rgbs[k])))
         assert np.array_equal(load_png_rgb(outs[k]), want)
+
+
+@pytest.mark.parametrize("a,b", [(4, 4), (2, 2), (2, 0), (1, 1), (1, 0), (4, 0)])
+def test_f1_any_width_uses_dword_kernel(csic, oracle, a, b):
+    """f = 1 with a width that is not a multiple of 4 (and therefore rows that are not 16-byte aligned):
+    served by k_dec<f1> (4-byte accesses, DPP hold, per-row broadcast on 4:x:0 odd rows), not k_generic."""
+    for W, H in [(1001, 37), (4095, 16), (13, 9)]:
+        argb = oracle.synth_frame(W * H, W)
+        for rounding in (0, 1):
+            want = oracle.process(_oparams(oracle, W, H, a, b, (3, 3, 2), 1, CSQ, rounding), argb)
+            with _plan(csic, W, H, a, b, (3, 3, 2), 1, CSQ, rounding) as pl:
+                assert pl.kernel_name.startswith("k_dec<") and ",f1," in pl.kernel_name, pl.kernel_name
+                assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
