@@ -40,6 +40,10 @@ CONFIGS = {
     "8k_444_f1": (8192, 8192, 4, 4, (8, 8, 8), 1, 1),
     "8k_420_f1": (8192, 8192, 2, 0, (3, 3, 2), 1, 1),
 }
+# AVG sampling extension (no reference counterpart): same shapes as cfg4 / cfg5, every input row is live
+AVG_CONFIGS = {"avg_8k_420_sf2": "cfg4", "avg_4k_420_sf4": "cfg5"}
+for _k, _v in AVG_CONFIGS.items():
+    CONFIGS[_k] = CONFIGS[_v]
 CSQ = (3, 1, 2)
 
 
@@ -145,11 +149,12 @@ def main():
     W, H, a, b, bits, f, fps = CONFIGS[args.config]
     # ---- this rank's stripe ---------------------------------------------------------------------
     gH = H * world if args.scaling == "weak" else H
-    gparams = csic.make_c_params(W, gH, a, b, *bits, f, CSQ)
+    sampling = csic.Sampling.AVG if args.config in AVG_CONFIGS else csic.Sampling.HOLD_DECIMATE
+    gparams = csic.make_c_params(W, gH, a, b, *bits, f, CSQ, sampling=sampling)
     r0, nr, o0, on = (C.c_int32() for _ in range(4))
     N.check(lib.csic_stripe_rows(C.byref(gparams), world, rank, C.byref(r0), C.byref(nr), C.byref(o0), C.byref(on)))
     sH = nr.value
-    plan = csic.Plan(csic.make_c_params(W, sH, a, b, *bits, f, CSQ), dev_index)
+    plan = csic.Plan(csic.make_c_params(W, sH, a, b, *bits, f, CSQ, sampling=sampling), dev_index)
     if args.variant >= 0:
         plan.tune(N.TUNE_VARIANT, args.variant)
     if args.no_vector:

@@ -7,7 +7,7 @@ ImageCompressionApp).  There is no CPU compute path in here.
 """
 from . import _native
 from ._native import CsicRuntimeError, IllegalArgumentException
-from .params import ImageProcessorParams, PixelFormat, ProcessingStep, Rounding, make_c_params
+from .params import ImageProcessorParams, PixelFormat, ProcessingStep, Rounding, Sampling, make_c_params
 from .compressor import ImageCompressorTop, ImageProcessor, Plan
 from .model import Image, ImageProcessorModel
 from .pipeline import FramePipeline
@@ -17,6 +17,6 @@ from . import app, compressor, distributed, model, params, pipeline
 
 __all__ = [
     "CsicRuntimeError", "IllegalArgumentException", "ImageProcessorParams", "PixelFormat", "ProcessingStep",
-    "Rounding", "make_c_params", "ImageCompressorTop", "ImageProcessor", "Plan", "Image", "ImageProcessorModel",
+    "Rounding", "Sampling", "make_c_params", "ImageCompressorTop", "ImageProcessor", "Plan", "Image", "ImageProcessorModel",
     "ImageCompressionApp", "FramePipeline", "Stripe", "StripedImageCompressorTop", "stripe_for_rank",
 ]

@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _native as N
-from .params import (ImageProcessorParams, PixelFormat, ProcessingStep, Rounding, make_c_params)
+from .params import (ImageProcessorParams, PixelFormat, ProcessingStep, Rounding, Sampling, make_c_params)
 
 
 def _is_torch_tensor(x) -> bool:
@@ -118,10 +118,12 @@ class ImageCompressorTop:
                  yTargetQuantBitsConfig: int, cbTargetQuantBitsConfig: int, crTargetQuantBitsConfig: int,
                  downFactorConfig: int,
                  op1Type: ProcessingStep, op2Type: ProcessingStep, op3Type: ProcessingStep,
-                 *, rounding: Rounding = Rounding.FLOOR_HW, device: int = 0):
+                 *, rounding: Rounding = Rounding.FLOOR_HW, device: int = 0,
+                 sampling: Sampling = Sampling.HOLD_DECIMATE):
         self.width, self.height = width, height
         self.ops = (ProcessingStep(op1Type), ProcessingStep(op2Type), ProcessingStep(op3Type))
         self.rounding, self.device = Rounding(rounding), device
+        self.sampling = Sampling(sampling)       # AVG = extension without a reference counterpart
         self._args = (width, height, chroma_param_a_config, chroma_param_b_config, yTargetQuantBitsConfig,
                       cbTargetQuantBitsConfig, crTargetQuantBitsConfig, downFactorConfig, self.ops)
         # construction-time require()s, before any device is touched (ImageCompressorTop.scala:27-31 etc.)
@@ -129,7 +131,8 @@ class ImageCompressorTop:
         self._plans = {}
 
     def _c_params(self, fmt: PixelFormat) -> N.CsicParams:
-        return make_c_params(*self._args, rounding=self.rounding, out_format=fmt, strict_divisible=False)
+        return make_c_params(*self._args, rounding=self.rounding, out_format=fmt, strict_divisible=False,
+                             sampling=self.sampling)
 
     def plan(self, fmt: PixelFormat = PixelFormat.ARGB8888) -> Plan:
         if fmt not in self._plans:

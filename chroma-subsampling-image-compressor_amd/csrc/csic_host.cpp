@@ -61,8 +61,11 @@ static int validate_impl(const csic_params *p)
     }
     if (p->rounding != CSIC_ROUND_FLOOR_HW && p->rounding != CSIC_ROUND_TRUNC_SW)
         return set_error(CSIC_EINVAL_ROUNDING, "rounding must be FLOOR_HW(0) or TRUNC_SW(1). Got %d", p->rounding);
-    if (p->sampling != CSIC_SAMPLING_HOLD_DECIMATE)
-        return set_error(CSIC_EINVAL_SAMPLING, "only HOLD_DECIMATE(0) sampling exists. Got %d", p->sampling);
+    if (p->sampling != CSIC_SAMPLING_HOLD_DECIMATE && p->sampling != CSIC_SAMPLING_AVG)
+        return set_error(CSIC_EINVAL_SAMPLING, "sampling must be HOLD_DECIMATE(0) or AVG(1). Got %d", p->sampling);
+    if (p->sampling == CSIC_SAMPLING_AVG &&
+        !(p->op[0] == CSIC_OP_CHROMA && p->op[1] == CSIC_OP_SPATIAL && p->op[2] == CSIC_OP_QUANT))
+        return set_error(CSIC_EINVAL_SAMPLING, "the AVG extension is defined for the order chroma -> spatial -> quant only");
     if (p->in_format != CSIC_FMT_ARGB8888)
         return set_error(CSIC_EINVAL_FORMAT, "in_format must be ARGB8888(0). Got %d", p->in_format);
     if (p->out_format != CSIC_FMT_ARGB8888 && p->out_format != CSIC_FMT_YCBCR888X)
@@ -147,8 +150,10 @@ int csic_algorithmic_bytes(const csic_params *p, int64_t *bytes)
     Geometry g;
     int st = derive_geometry(p, &g);
     if (st != CSIC_OK) return st;
-    // every byte of each input row that holds a surviving pixel + the output
-    *bytes = 4ll * g.W * g.Ho + 4ll * g.Wo * g.Ho;
+    // every byte of each input row that holds a surviving pixel + the output;
+    // with AVG sampling every input row is live: A_avg = 4*W*H + 4*Wo*Ho
+    if (p->sampling == CSIC_SAMPLING_AVG) *bytes = 4ll * g.W * g.H + 4ll * g.Wo * g.Ho;
+    else                                  *bytes = 4ll * g.W * g.Ho + 4ll * g.Wo * g.Ho;
     clear_error();
     return CSIC_OK;
 }

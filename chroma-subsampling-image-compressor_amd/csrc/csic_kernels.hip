@@ -129,13 +129,10 @@ struct ChromaTerm {
     uint32_t ycc_hi;     // YCC output: Cb << 8 | Cr << 16
 };
 
-template <int ROUND, int FMT>
-__device__ __forceinline__ ChromaTerm chroma_term(uint32_t cpx, uint32_t mcb, uint32_t mcr)
+// from already quantised Cb, Cr
+template <int FMT>
+__device__ __forceinline__ ChromaTerm chroma_term_q(uint32_t cb, uint32_t cr)
 {
-    uint32_t cb, cr;
-    fwd_c<ROUND>(cpx, cb, cr);
-    cb &= mcb;                                          // quantiser, ColorQuantizer.scala:43-44
-    cr &= mcr;
     ChromaTerm t;
     if (FMT == F_ARGB) {
         t.kr = __mul24((int)cr, 409) - 52224;
@@ -149,12 +146,20 @@ __device__ __forceinline__ ChromaTerm chroma_term(uint32_t cpx, uint32_t mcb, ui
     return t;
 }
 
+template <int ROUND, int FMT>
+__device__ __forceinline__ ChromaTerm chroma_term(uint32_t cpx, uint32_t mcb, uint32_t mcr)
+{
+    uint32_t cb, cr;
+    fwd_c<ROUND>(cpx, cb, cr);
+    return chroma_term_q<FMT>(cb & mcb, cr & mcr);      // quantiser, ColorQuantizer.scala:43-44
+}
+
 __device__ __forceinline__ int clamp_u8(int v) { return min(max(v, 0), 255); }   // -> v_med3_i32
 
+// from an already quantised Y
 template <int FMT>
-__device__ __forceinline__ uint32_t finish(uint32_t ypx, uint32_t my, const ChromaTerm &t)
+__device__ __forceinline__ uint32_t finish_y(uint32_t y, const ChromaTerm &t)
 {
-    const uint32_t y = fwd_y(ypx) & my;                 // quantiser, ColorQuantizer.scala:42
     if (FMT == F_ARGB) {
         const int yy = __mul24((int)y, 298);
         const int r = clamp_u8((yy + t.kr) >> 8);
@@ -164,6 +169,12 @@ __device__ __forceinline__ uint32_t finish(uint32_t ypx, uint32_t my, const Chro
     } else {
         return y | t.ycc_hi;
     }
+}
+
+template <int FMT>
+__device__ __forceinline__ uint32_t finish(uint32_t ypx, uint32_t my, const ChromaTerm &t)
+{
+    return finish_y<FMT>(fwd_y(ypx) & my, t);           // quantiser, ColorQuantizer.scala:42
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -345,6 +356,147 @@ __global__ void __launch_bounds__(256) k_dec2v(KArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// AVG sampling extension (CSIC_SAMPLING_AVG) -- NOT reference semantics.
+// Box-filter chroma (h x v blocks) followed by f x f average pooling, order chroma -> spatial -> quant,
+// integer rounding (sum + n/2) >> log2 n per stage, 8-bit values between stages, edge coordinates
+// clamped.  This is what the reference's README and the north star describe; the reference code itself
+// does sample-and-hold + decimation (k_dec / k_f1x4 above).  Normative statement: oracle/csic_oracle.c
+// orc_process_avg.  All input rows are live here: algorithmic bytes = 4*W*H + 4*Wo*Ho.
+//
+// k_avg (fast path, W % TW == 0, H % TH == 0, 16-byte aligned): one lane owns a 4-pixel-wide, TH-row
+// tile (TH = max(v, f)) = TH dense 16-byte loads, so every chroma block and every pooling block with
+// f <= 4 lies inside one lane's registers -- no LDS line buffer and no cross-lane traffic is needed.
+// f = 8 spans two lanes: each sums its 4 x 8 half and the halves meet through one DPP quad_perm swap.
+// ------------------------------------------------------------------------------------------------
+template <int ROUND, int FMT, int F, int HH, int VV, bool NT>
+__global__ void __launch_bounds__(256) k_avg(KArgs a)
+{
+    constexpr int TH = (F > VV) ? F : VV;               // tile rows per lane
+    constexpr int NLOG = (HH == 4 ? 2 : HH == 2 ? 1 : 0) + (VV == 2 ? 1 : 0);
+    constexpr int FLOG2 = (F == 8 ? 6 : F == 4 ? 4 : F == 2 ? 2 : 0);
+    pin_args(a);
+    const int x4 = blockIdx.x * a.bdx + threadIdx.x;
+    if (x4 >= (a.W >> 2)) return;
+    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
+    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const int ntr = a.H / TH;
+    for (int tr = blockIdx.y * a.bdy + threadIdx.y; tr < ntr; tr += a.row_step) {
+        u32x4 p[TH];
+#pragma unroll
+        for (int i = 0; i < TH; ++i) p[i] = ld4<NT>(in + (int64_t)(tr * TH + i) * a.W + 4 * x4);
+        uint32_t Y[TH][4], Cb[TH][4], Cr[TH][4];
+#pragma unroll
+        for (int i = 0; i < TH; ++i) {
+            const uint32_t px[4] = {p[i].x, p[i].y, p[i].z, p[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Y[i][j] = fwd_y(px[j]);
+                fwd_c<ROUND>(px[j], Cb[i][j], Cr[i][j]);
+            }
+        }
+        // chroma stage: HH x VV block averages, written back to every pixel of the block
+#pragma unroll
+        for (int bi = 0; bi < TH; bi += VV) {
+#pragma unroll
+            for (int bj = 0; bj < 4; bj += HH) {
+                uint32_t sb = 0, sr = 0;
+#pragma unroll
+                for (int i = 0; i < VV; ++i)
+#pragma unroll
+                    for (int j = 0; j < HH; ++j) { sb += Cb[bi + i][bj + j]; sr += Cr[bi + i][bj + j]; }
+                sb = (sb + ((HH * VV) >> 1)) >> NLOG;
+                sr = (sr + ((HH * VV) >> 1)) >> NLOG;
+#pragma unroll
+                for (int i = 0; i < VV; ++i)
+#pragma unroll
+                    for (int j = 0; j < HH; ++j) { Cb[bi + i][bj + j] = sb; Cr[bi + i][bj + j] = sr; }
+            }
+        }
+        if (F <= 4) {
+            constexpr int FF = (F <= 4) ? F : 4;        // (keeps the F = 8 instantiation well-formed)
+            constexpr int NOX = 4 / FF, NOY = TH / FF;  // output pixels per tile
+#pragma unroll
+            for (int oi = 0; oi < NOY; ++oi) {
+                uint32_t o[NOX];
+#pragma unroll
+                for (int oj = 0; oj < NOX; ++oj) {
+                    uint32_t sy = 0, sb = 0, sr = 0;
+#pragma unroll
+                    for (int i = 0; i < FF; ++i)
+#pragma unroll
+                        for (int j = 0; j < FF; ++j) {
+                            sy += Y[oi * FF + i][oj * FF + j]; sb += Cb[oi * FF + i][oj * FF + j]; sr += Cr[oi * FF + i][oj * FF + j];
+                        }
+                    sy = ((sy + ((FF * FF) >> 1)) >> FLOG2) & a.my;
+                    sb = ((sb + ((FF * FF) >> 1)) >> FLOG2) & a.mcb;
+                    sr = ((sr + ((FF * FF) >> 1)) >> FLOG2) & a.mcr;
+                    o[oj] = finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr));
+                }
+                uint32_t *op = out + (int64_t)(tr * NOY + oi) * a.Wo + x4 * NOX;
+                if (NOX == 4) { const u32x4 ov = {o[0], o[1 % NOX], o[2 % NOX], o[3 % NOX]}; st4<NT>(op, ov); }
+                else if (NOX == 2) { const u32x2 ov = {o[0], o[1 % NOX]}; st2<NT>(op, ov); }
+                else st1<NT>(op, o[0]);
+            }
+        } else {
+            // F = 8: this lane's 4 x 8 half, then the neighbour's through a quad_perm [1,0,3,2] swap
+            uint32_t sy = 0, sb = 0, sr = 0;
+#pragma unroll
+            for (int i = 0; i < TH; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sy += Y[i][j]; sb += Cb[i][j]; sr += Cr[i][j]; }
+            sy += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
+            sb += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sb, 0xB1, 0xF, 0xF, false);
+            sr += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sr, 0xB1, 0xF, 0xF, false);
+            if ((x4 & 1) == 0) {
+                sy = ((sy + 32) >> 6) & a.my;
+                sb = ((sb + 32) >> 6) & a.mcb;
+                sr = ((sr + 32) >> 6) & a.mcr;
+                st1<NT>(out + (int64_t)tr * a.Wo + (x4 >> 1), finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr)));
+            }
+        }
+    }
+}
+
+// Any shape: one output pixel per lane, clamped coordinates, orc_process_avg verbatim.
+template <int ROUND, int FMT>
+__global__ void __launch_bounds__(256) k_avg_generic(KArgs a)
+{
+    pin_args(a);
+    const int co = blockIdx.x * a.bdx + threadIdx.x;
+    if (co >= a.Wo) return;
+    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
+    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const int h = a.hmask + 1, v = a.vmask + 1, f = a.f;
+    const int nlog = (h == 4 ? 2 : h == 2 ? 1 : 0) + (v == 2 ? 1 : 0);
+    const int flog2 = 2 * a.sc_shift;
+    for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += a.row_step) {
+        uint32_t sy = 0, sb = 0, sr = 0;
+        for (int i = 0; i < f; ++i) {
+            for (int j = 0; j < f; ++j) {
+                const int r = min(ro * f + i, a.H - 1), c = min(co * f + j, a.W - 1);
+                sy += fwd_y(in[(int64_t)r * a.W + c]);
+                const int r0 = r & ~a.vmask, c0 = c & ~a.hmask;
+                uint32_t ab = 0, ar = 0;
+                for (int ii = 0; ii < v; ++ii) {
+                    for (int jj = 0; jj < h; ++jj) {
+                        const int rr = min(r0 + ii, a.H - 1), cc = min(c0 + jj, a.W - 1);
+                        uint32_t cb, cr;
+                        fwd_c<ROUND>(in[(int64_t)rr * a.W + cc], cb, cr);
+                        ab += cb; ar += cr;
+                    }
+                }
+                sb += (ab + ((h * v) >> 1)) >> nlog;
+                sr += (ar + ((h * v) >> 1)) >> nlog;
+            }
+        }
+        sy = ((sy + ((f * f) >> 1)) >> flog2) & a.my;
+        sb = ((sb + ((f * f) >> 1)) >> flog2) & a.mcb;
+        sr = ((sr + ((f * f) >> 1)) >> flog2) & a.mcr;
+        out[(int64_t)ro * a.Wo + co] = finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_generic: any parameters, one output pixel per lane (SURVEY.md App. A.3 / A.4 verbatim)
 // ------------------------------------------------------------------------------------------------
 template <int ROUND, int FMT>
@@ -409,7 +561,7 @@ __global__ void __launch_bounds__(256) k_checksum(const uint32_t *src, int64_t n
 // ------------------------------------------------------------------------------------------------
 using KernelFn = void (*)(KArgs);
 
-enum Family { FAM_F1X4, FAM_DEC, FAM_DEC2V1, FAM_DEC2V2, FAM_GENERIC };
+enum Family { FAM_F1X4, FAM_DEC, FAM_DEC2V1, FAM_DEC2V2, FAM_GENERIC, FAM_AVG, FAM_AVG_GENERIC };
 
 } // namespace csic
 
@@ -478,6 +630,28 @@ static KernelFn pick_dec(int f, int hold, bool srows)
     return pick_dec_f<ROUND, FMT, 8, NT>(hold, srows);
 }
 
+template <int ROUND, int FMT, int F, bool NT>
+static KernelFn pick_avg_f(int h, int v)
+{
+    if (v == 1) {
+        if (h == 1) return k_avg<ROUND, FMT, F, 1, 1, NT>;
+        if (h == 2) return k_avg<ROUND, FMT, F, 2, 1, NT>;
+        return k_avg<ROUND, FMT, F, 4, 1, NT>;
+    }
+    if (h == 1) return k_avg<ROUND, FMT, F, 1, 2, NT>;
+    if (h == 2) return k_avg<ROUND, FMT, F, 2, 2, NT>;
+    return k_avg<ROUND, FMT, F, 4, 2, NT>;
+}
+
+template <int ROUND, int FMT, bool NT>
+static KernelFn pick_avg(int f, int h, int v)
+{
+    if (f == 1) return pick_avg_f<ROUND, FMT, 1, NT>(h, v);
+    if (f == 2) return pick_avg_f<ROUND, FMT, 2, NT>(h, v);
+    if (f == 4) return pick_avg_f<ROUND, FMT, 4, NT>(h, v);
+    return pick_avg_f<ROUND, FMT, 8, NT>(h, v);
+}
+
 // Can the k_dec family handle this geometry?  Chroma before spatial: always, except that a hold across
 // lanes (4:1:1 with f = 2) needs whole quads in a row.  Spatial before chroma: only when chroma rows
 // coincide with groups of decimated rows (f | W) and the in-row hold is lane-aligned (h | Wo).
@@ -498,6 +672,24 @@ static void select_rf(csic_plan *pl)
     const char *fn = FMT == F_ARGB ? "argb" : "ycc";
     const bool nt = !pl->no_nt;
     const char *ntn = nt ? "nt" : "cached";
+    if (pl->p.sampling == CSIC_SAMPLING_AVG) {
+        const int th = g.f > g.v ? g.f : g.v;
+        const int tw = g.f == 8 ? 8 : 4;
+        if (!pl->force_generic && !pl->no_vec && g.W % tw == 0 && g.H % th == 0) {
+            pl->fam = FAM_AVG;
+            pl->fn = nt ? pick_avg<ROUND, FMT, true>(g.f, g.h, g.v) : pick_avg<ROUND, FMT, false>(g.f, g.h, g.v);
+            pl->units_per_row = g.W / 4;
+            pl->k_per_lane = 1;
+            snprintf(pl->name, sizeof pl->name, "k_avg<%s,%s,f%d,h%d,v%d,%s>", rn, fn, g.f, g.h, g.v, ntn);
+        } else {
+            pl->fam = FAM_AVG_GENERIC;
+            pl->fn = k_avg_generic<ROUND, FMT>;
+            pl->units_per_row = g.Wo;
+            pl->k_per_lane = 1;
+            snprintf(pl->name, sizeof pl->name, "k_avg_generic<%s,%s>", rn, fn);
+        }
+        return;
+    }
     // f = 1: the 16-byte kernel wins for v = 1 (8192^2 4:4:4: 84.1 vs 88.0 us); for 4:x:0 the 4-byte k_dec<f1>
     // with its per-row broadcast wins (86.2 vs 89-91 us), unless the frame is too narrow for it.
     const bool f1x4_ok = !pl->force_generic && !pl->no_vec && g.f == 1 && g.W % 4 == 0;
@@ -570,7 +762,7 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
     KernelFn fn = pl->fn;
     int units = pl->units_per_row, kpl = pl->k_per_lane;
     // The vector kernels need 16-byte aligned frame bases; otherwise take the 4-byte-access kernels.
-    const bool vec = (fam == FAM_F1X4 || fam == FAM_DEC2V1 || fam == FAM_DEC2V2);
+    const bool vec = (fam == FAM_F1X4 || fam == FAM_DEC2V1 || fam == FAM_DEC2V2 || fam == FAM_AVG);
     if (vec && ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15u)) {
         csic_plan tmp = *pl;
         tmp.no_vec = 1;
@@ -591,7 +783,7 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
     a.bc_row_off = g.last_sample_col / g.Wo;             // only meaningful (and only used) when f | W
     a.bc_col_in = (g.last_sample_col % g.Wo) * g.f;
 
-    const int rows = (fam == FAM_F1X4) ? g.H : g.Ho;
+    const int rows = (fam == FAM_F1X4) ? g.H : (fam == FAM_AVG) ? g.H / (g.f > g.v ? g.f : g.v) : g.Ho;
     const int lanes_x = (units + kpl - 1) / kpl;
     int bx = pow2_ceil(lanes_x);
     if (bx > 256) bx = 256;

@@ -37,13 +37,19 @@ class Rounding(enum.IntEnum):
     TRUNC_SW = N.ROUND_TRUNC_SW      # YCbCrUtils.rgbToYCbCr: (x + 128) / 256
 
 
+class Sampling(enum.IntEnum):
+    HOLD_DECIMATE = 0                # the reference's semantics (default; everything "bit-exact" means this)
+    AVG = 1                          # extension: box-filter chroma + average pooling, no reference counterpart
+
+
 class PixelFormat(enum.IntEnum):
     ARGB8888 = N.FMT_ARGB8888
     YCBCR888X = N.FMT_YCBCR888X
 
 
 def make_c_params(width, height, a, b, yq, cbq, crq, sf, ops, rounding=Rounding.FLOOR_HW,
-                  out_format=PixelFormat.ARGB8888, strict_divisible=False) -> N.CsicParams:
+                  out_format=PixelFormat.ARGB8888, strict_divisible=False,
+                  sampling=Sampling.HOLD_DECIMATE) -> N.CsicParams:
     p = N.CsicParams()
     p.width, p.height = int(width), int(height)
     p.chroma_a, p.chroma_b = int(a), int(b)
@@ -52,7 +58,7 @@ def make_c_params(width, height, a, b, yq, cbq, crq, sf, ops, rounding=Rounding.
     for k in range(3):
         p.op[k] = int(ops[k])
     p.rounding = int(rounding)
-    p.sampling = 0
+    p.sampling = int(sampling)
     p.in_format = N.FMT_ARGB8888
     p.out_format = int(out_format)
     p.strict_divisible = 1 if strict_divisible else 0

@@ -71,9 +71,15 @@ typedef enum csic_status {
 #define CSIC_ROUND_FLOOR_HW 0 /* RTL + ReferenceModel: (x+128) >> 8     RGB2YCbCr.scala:50-65       */
 #define CSIC_ROUND_TRUNC_SW 1 /* YCbCrUtils.rgbToYCbCr: (x+128) / 256   RGB2YCbCr.scala:111-118     */
 
-/* Sampling semantics.  Only the reference-exact one exists: chroma sample-and-hold
- * (ChromaSubsampler.scala:47-65) and top-left decimation (SpatialDownsampler.scala:33-55). */
+/* Sampling semantics.
+ * HOLD_DECIMATE (default) is the reference's: chroma sample-and-hold (ChromaSubsampler.scala:47-65) and
+ *   top-left decimation (SpatialDownsampler.scala:33-55).  Everything "bit-exact" refers to this mode.
+ * AVG is an EXTENSION with no counterpart in the reference code (its README and the project brief describe
+ *   it): box-filter chroma over h x v blocks, then f x f average pooling, each (sum + n/2) >> log2 n on 8-bit
+ *   values, edge coordinates clamped; defined for op = {CHROMA, SPATIAL, QUANT} only.  Its normative
+ *   statement is oracle/csic_oracle.c:orc_process_avg; it has no reference parity by construction. */
 #define CSIC_SAMPLING_HOLD_DECIMATE 0
+#define CSIC_SAMPLING_AVG           1
 
 #define CSIC_FMT_ARGB8888  0
 #define CSIC_FMT_YCBCR888X 1  /* out_format only */
@@ -92,7 +98,7 @@ typedef struct csic_params {
     int32_t factor;                      /* spatial decimation factor 1,2,4,8                         */
     int32_t op[3];                       /* permutation of CSIC_OP_{SPATIAL,QUANT,CHROMA}             */
     int32_t rounding;                    /* CSIC_ROUND_*                                              */
-    int32_t sampling;                    /* CSIC_SAMPLING_HOLD_DECIMATE                               */
+    int32_t sampling;                    /* CSIC_SAMPLING_HOLD_DECIMATE (reference) or CSIC_SAMPLING_AVG  */
     int32_t in_format, out_format;       /* CSIC_FMT_*                                                */
     int32_t strict_divisible;            /* 1 = enforce ImageProcessorParams' divisibility require()  */
 } csic_params;
@@ -117,7 +123,8 @@ int  csic_out_dims(const csic_params *p, int32_t *out_width, int32_t *out_height
 
 /* Algorithmic HBM bytes of one frame, the roofline numerator of SURVEY.md 8(d):
  *   A = 4*W*ceil(H/f) + 4*ceil(W/f)*ceil(H/f)
- * (every input row that holds a surviving pixel, plus the output; rows r % f != 0 are dead). */
+ * (every input row that holds a surviving pixel, plus the output; rows r % f != 0 are dead).
+ * With CSIC_SAMPLING_AVG every row is live: A = 4*W*H + 4*ceil(W/f)*ceil(H/f). */
 int  csic_algorithmic_bytes(const csic_params *p, int64_t *bytes);
 
 /* Row-stripe partition for `nranks` devices.  Stripe boundaries are aligned to

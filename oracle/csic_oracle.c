@@ -265,6 +265,73 @@ long orc_process_closed(const orc_params *p, const uint32_t *in, uint32_t *out)
     return orc_process_closed_rows(p, in, out, 0, ho);
 }
 
+/* ------------------------------------------------------------------------- */
+/* AVG sampling extension (NOT reference semantics)                            */
+/* ------------------------------------------------------------------------- */
+/* The reference's chroma stage is sample-and-hold and its spatial stage is decimation
+ * (ChromaSubsampler.scala:47-65, SpatialDownsampler.scala:33-55); its README and the project's
+ * north star describe box-filter averaging instead.  This is the build-defined integer
+ * specification of that variant -- there is nothing in the reference to be bit-exact against
+ * ("parity unpinned"); this function is the normative statement the HIP kernels are tested on.
+ *   order is fixed: forward -> chroma average -> spatial average -> quantise -> (inverse)
+ *   chroma: block (r - r % v, c - c % h) of h x v pixels, coordinates clamped to the image,
+ *           Cb' = (sum + n/2) >> log2(n), n = h*v; same for Cr; Y passes through
+ *   spatial: output (ro, co) = per channel (sum over the f x f block at (ro*f, co*f), coordinates
+ *           clamped, of the chroma-stage output + f*f/2) >> (2 log2 f)
+ * Stages exchange 8-bit values, like the streaming pipeline would. */
+static int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+
+long orc_process_avg(const orc_params *p, const uint32_t *in, uint32_t *out)
+{
+    if (orc_validate(p) != 0) return -1;
+    if (!(p->op[0] == ORC_OP_CHROMA && p->op[1] == ORC_OP_SPATIAL && p->op[2] == ORC_OP_QUANT)) return -1;
+    const long W = p->width, H = p->height;
+    const int f = p->factor, h = 4 / p->chroma_a, v = (p->chroma_b == 0) ? 2 : 1;
+    const int nlog = ilog2(h * v), flog2 = 2 * ilog2(f);
+    int32_t wo, ho; orc_out_dims(p, &wo, &ho);
+    long n = 0;
+    for (long ro = 0; ro < ho; ++ro) {
+        for (long co = 0; co < wo; ++co) {
+            int sy = 0, scb = 0, scr = 0;
+            for (int i = 0; i < f; ++i) {
+                for (int j = 0; j < f; ++j) {
+                    long r = ro * f + i, c = co * f + j;
+                    if (r > H - 1) r = H - 1;
+                    if (c > W - 1) c = W - 1;
+                    /* chroma-stage output at (r, c) */
+                    uint32_t px = in[r * W + c];
+                    int y, cb, cr;
+                    orc_rgb2ycbcr((px >> 16) & 0xFF, (px >> 8) & 0xFF, px & 0xFF, p->rounding, &y, &cb, &cr);
+                    long r0 = r - r % v, c0 = c - c % h;
+                    int acb = 0, acr = 0;
+                    for (int ii = 0; ii < v; ++ii) {
+                        for (int jj = 0; jj < h; ++jj) {
+                            long rr = r0 + ii, cc = c0 + jj;
+                            if (rr > H - 1) rr = H - 1;
+                            if (cc > W - 1) cc = W - 1;
+                            uint32_t q = in[rr * W + cc];
+                            int y2, cb2, cr2;
+                            orc_rgb2ycbcr((q >> 16) & 0xFF, (q >> 8) & 0xFF, q & 0xFF, p->rounding, &y2, &cb2, &cr2);
+                            acb += cb2; acr += cr2;
+                        }
+                    }
+                    sy += y;
+                    scb += (acb + ((h * v) >> 1)) >> nlog;
+                    scr += (acr + ((h * v) >> 1)) >> nlog;
+                }
+            }
+            ycc_t o;
+            o.y  = (sy  + ((f * f) >> 1)) >> flog2;
+            o.cb = (scb + ((f * f) >> 1)) >> flog2;
+            o.cr = (scr + ((f * f) >> 1)) >> flog2;
+            orc_quantize(o.y, o.cb, o.cr, p->y_bits, p->cb_bits, p->cr_bits, &o.y, &o.cb, &o.cr);
+            out[ro * wo + co] = pack_out(p, o);
+            ++n;
+        }
+    }
+    return n;
+}
+
 /* Row-parallel closed form on `nthreads` POSIX threads (output rows are independent): the
  * "all host cores" CPU baseline of BASELINE.md section 2.  Same results as orc_process_closed. */
 typedef struct { const orc_params *p; const uint32_t *in; uint32_t *out; int32_t ro0, ro1; long n; } mt_job;

@@ -77,6 +77,10 @@ long orc_process_closed(const orc_params *p, const uint32_t *in, uint32_t *out);
 long orc_process_closed_rows(const orc_params *p, const uint32_t *in, uint32_t *out,
                              int32_t ro0, int32_t ro1);
 
+/* AVG sampling extension: box-filter chroma + average pooling, order chroma->spatial->quant only.
+ * Build-defined semantics with NO counterpart in the reference ("parity unpinned"); see csic_oracle.c. */
+long orc_process_avg(const orc_params *p, const uint32_t *in, uint32_t *out);
+
 /* Closed form, output rows split over `nthreads` POSIX threads (CPU baseline on all host cores). */
 long orc_process_closed_mt(const orc_params *p, const uint32_t *in, uint32_t *out, int nthreads);
 

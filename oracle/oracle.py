@@ -84,7 +84,7 @@ def lib() -> C.CDLL:
         L.orc_validate.restype = C.c_int
         L.orc_out_dims.argtypes = [C.POINTER(_Params), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.orc_out_dims.restype = None
-        for fn in (L.orc_process_stream, L.orc_process_closed):
+        for fn in (L.orc_process_stream, L.orc_process_closed, L.orc_process_avg):
             fn.argtypes = [C.POINTER(_Params), u32p, u32p]
             fn.restype = C.c_long
         L.orc_process_closed_mt.argtypes = [C.POINTER(_Params), u32p, u32p, C.c_int]
@@ -151,7 +151,8 @@ def process(p: OracleParams, argb: np.ndarray, form: str = "stream") -> np.ndarr
         raise ValueError(f"invalid parameters (oracle code {validate(p)})")
     wo, ho = out_dims(p)
     out = np.empty(wo * ho, dtype=np.uint32)
-    fn = {"stream": lib().orc_process_stream, "closed": lib().orc_process_closed}[form]
+    fn = {"stream": lib().orc_process_stream, "closed": lib().orc_process_closed,
+          "avg": lib().orc_process_avg}[form]      # "avg" = the AVG extension, not reference semantics
     n = fn(C.byref(p.c()), _u32(a), _u32(out))
     if n != wo * ho:
         raise RuntimeError(f"oracle emitted {n} pixels, expected {wo * ho}")

@@ -17,6 +17,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _ensure_native_built():
+    """The .so files are build artefacts (git-ignored).  On a fresh checkout build them before any test
+    module imports the package: hipcc cross-compiles gfx950 without a GPU, gcc builds the oracle."""
+    import subprocess
+    pkg = os.path.join(ROOT, "chroma-subsampling-image-compressor_amd")
+    lib = os.path.join(pkg, "libcsic_hip.so")
+    srcs = [os.path.join(pkg, "csrc", f) for f in os.listdir(os.path.join(pkg, "csrc"))
+            if f.endswith((".hip", ".cpp", ".h"))] + [os.path.join(ROOT, "include", "csic.h")]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(pkg, "csrc"), "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+
+
+_ensure_native_built()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

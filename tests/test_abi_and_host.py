@@ -66,6 +66,19 @@ def test_validation_codes(kw, status):
     assert ei.value.status == status and str(ei.value).startswith("requirement failed")
 
 
+def test_avg_extension_validation():
+    """AVG sampling is an extension defined for the north-star order only."""
+    ok = csic.make_c_params(16, 16, 2, 0, 3, 3, 2, 2, CSQ, sampling=csic.Sampling.AVG)
+    assert N.lib().csic_validate(C.byref(ok)) == 0
+    b = C.c_int64()
+    assert N.lib().csic_algorithmic_bytes(C.byref(ok), C.byref(b)) == 0 and b.value == 4 * 16 * 16 + 4 * 8 * 8
+    for op in [(1, 2, 3), (3, 2, 1), (2, 3, 1)]:
+        bad = csic.make_c_params(16, 16, 2, 0, 3, 3, 2, 2, op, sampling=csic.Sampling.AVG)
+        assert N.lib().csic_validate(C.byref(bad)) == N.EINVAL_SAMPLING
+    worse = csic.make_c_params(16, 16, 2, 0, 3, 3, 2, 2, CSQ, sampling=2)
+    assert N.lib().csic_validate(C.byref(worse)) == N.EINVAL_SAMPLING
+
+
 def test_valid_params_clear_last_error():
     p = csic.make_c_params(16, 16, 2, 0, 3, 3, 2, 2, CSQ)
     assert N.lib().csic_validate(C.byref(p)) == 0
@@ -176,12 +189,21 @@ def test_compute_fails_loudly_without_a_gpu():
 
 
 def test_product_package_never_touches_the_oracle():
+    """No include, import, load or call of anything under oracle/ from the product tree (comments may cite
+    the oracle as the normative statement of the AVG extension)."""
+    import re
     pkg = os.path.join(ROOT, "chroma-subsampling-image-compressor_amd")
-    for dirpath, _, files in os.walk(pkg):
-        for fn in files:
-            if fn.endswith((".py", ".hip", ".cpp", ".h", ".scala", ".c")):
-                text = open(os.path.join(dirpath, fn), errors="ignore").read()
-                assert "csic_oracle" not in text and "from oracle" not in text and "import oracle" not in text, fn
+    uses = re.compile(r'#\s*include\s*[<"][^">]*csic_oracle|libcsic_oracle|\bfrom\s+oracle\b|\bimport\s+oracle\b|\borc_[a-z0-9_]+\s*\(')
+    for tree in (pkg, os.path.join(ROOT, "include")):
+        for dirpath, _, files in os.walk(tree):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".cpp", ".h", ".hpp", ".scala", ".c")):
+                    text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                    assert not uses.search(text), fn
+    # and the shared library has no dependency on it
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", N.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in needed
 
 
 # ---- host I/O + CLI mirror (no device needed) -------------------------------------------------------

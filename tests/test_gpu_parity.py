@@ -458,3 +458,47 @@ def test_f1_any_width_uses_dword_kernel(csic, oracle, a, b):
             with _plan(csic, W, H, a, b, (3, 3, 2), 1, CSQ, rounding) as pl:
                 assert pl.kernel_name.startswith("k_dec<") and ",f1," in pl.kernel_name, pl.kernel_name
                 assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
+
+
+# ---- AVG sampling extension: no reference parity by construction; checked against its own oracle -------
+def _avg_plan(csic, W, H, a, b, bits, f, rounding=0, fmt=0):
+    cp = csic.make_c_params(W, H, a, b, *bits, f, CSQ, rounding=rounding, out_format=fmt, sampling=csic.Sampling.AVG)
+    return csic.Plan(cp, 0)
+
+
+@pytest.mark.parametrize("a,b", [(4, 4), (2, 2), (2, 0), (1, 1), (1, 0), (4, 0)])
+@pytest.mark.parametrize("f", [1, 2, 4, 8])
+def test_avg_extension_fast_path(csic, oracle, a, b, f):
+    W, H = 512, 64
+    argb = oracle.synth_frame(W * H, 31 * f + a)
+    for rounding, fmt in ((0, 0), (1, 1)):
+        want = oracle.process(_oparams(oracle, W, H, a, b, (6, 5, 5), f, CSQ, rounding, fmt), argb, form="avg")
+        with _avg_plan(csic, W, H, a, b, (6, 5, 5), f, rounding, fmt) as pl:
+            assert pl.kernel_name.startswith("k_avg<"), pl.kernel_name
+            assert np.array_equal(pl.process_host(argb), want), pl.kernel_name
+            pl.tune(csic._native.TUNE_FORCE_GENERIC, 1)
+            assert pl.kernel_name.startswith("k_avg_generic")
+            assert np.array_equal(pl.process_host(argb), want), pl.kernel_name
+
+
+def test_avg_extension_random_shapes(csic, oracle):
+    rng = np.random.default_rng(77)
+    for _ in range(120):
+        W, H = int(rng.integers(1, 70)), int(rng.integers(1, 40))
+        if rng.random() < 0.5:
+            W, H = (W + 7) // 8 * 8, (H + 7) // 8 * 8
+        a, b = [(4, 4), (2, 2), (2, 0), (1, 1), (4, 0), (1, 0)][int(rng.integers(0, 6))]
+        f = int(rng.choice([1, 2, 4, 8]))
+        bits = tuple(int(x) for x in rng.integers(1, 9, 3))
+        argb = rng.integers(0, 1 << 32, W * H, dtype=np.uint32)
+        want = oracle.process(_oparams(oracle, W, H, a, b, bits, f), argb, form="avg")
+        with _avg_plan(csic, W, H, a, b, bits, f) as pl:
+            assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H, a, b, f)
+
+
+def test_avg_extension_rejects_other_orders(csic):
+    with pytest.raises(csic.IllegalArgumentException):
+        csic.ImageCompressorTop(16, 16, 2, 0, 8, 8, 8, 2, 1, 2, 3, sampling=csic.Sampling.AVG)
+    top = csic.ImageCompressorTop(16, 16, 2, 0, 8, 8, 8, 2, 3, 1, 2, sampling=csic.Sampling.AVG)
+    assert top.process(np.zeros((16, 16), np.uint32)).shape == (8, 8)
+    top.close()

@@ -83,3 +83,46 @@ def test_multithreaded_closed_form_matches(oracle):
         want = oracle.process(p, argb, "stream")
         for nt in (1, 3, 8, 64):
             assert np.array_equal(oracle.process_mt(p, argb, nt), want)
+
+
+def test_avg_extension_oracle_properties(oracle):
+    """AVG is build-defined (no reference parity); pin its defining properties: identity with the
+    reference semantics at 4:4:4/f=1, constants are fixed points, means are preserved up to rounding,
+    and an independent numpy restatement agrees."""
+    rng = np.random.default_rng(9)
+    W, H = 24, 20
+    argb = rng.integers(0, 1 << 32, W * H, dtype=np.uint32)
+    p0 = oracle.OracleParams(width=W, height=H)
+    assert np.array_equal(oracle.process(p0, argb, "avg"), oracle.process(p0, argb, "closed"))
+    for (a, b, f) in [(2, 0, 2), (2, 2, 4), (1, 1, 2), (1, 0, 8), (4, 4, 2), (2, 0, 1)]:
+        p = oracle.OracleParams(width=W, height=H, chroma_a=a, chroma_b=b, factor=f, out_format=oracle.FMT_YCC)
+        got = oracle.process(p, argb, "avg")
+        # numpy restatement with the same clamped-coordinate block sums
+        ycc = oracle.process(oracle.OracleParams(width=W, height=H, out_format=oracle.FMT_YCC), argb, "closed")
+        Y, Cb, Cr = ycc & 0xFF, (ycc >> 8) & 0xFF, (ycc >> 16) & 0xFF
+        h, v = 4 // a, (2 if b == 0 else 1)
+        rr, cc = np.arange(H), np.arange(W)
+
+        def block_avg(ch, bh, bw):
+            acc = np.zeros((H, W), np.int64)
+            r0, c0 = rr - rr % bh, cc - cc % bw
+            for i in range(bh):
+                for j in range(bw):
+                    acc += ch[np.minimum(r0 + i, H - 1)][:, np.minimum(c0 + j, W - 1)].astype(np.int64)
+            return (acc + (bh * bw) // 2) >> int(np.log2(bh * bw))
+
+        Cb2, Cr2 = block_avg(Cb, v, h), block_avg(Cr, v, h)
+        ho, wo = -(-H // f), -(-W // f)
+
+        def pool(ch):
+            acc = np.zeros((ho, wo), np.int64)
+            for i in range(f):
+                for j in range(f):
+                    acc += ch[np.minimum(np.arange(ho) * f + i, H - 1)][:, np.minimum(np.arange(wo) * f + j, W - 1)]
+            return (acc + (f * f) // 2) >> int(2 * np.log2(f))
+
+        want = pool(Y.astype(np.int64)) | (pool(Cb2) << 8) | (pool(Cr2) << 16)
+        assert np.array_equal(got.astype(np.int64), want), (a, b, f)
+    const = np.full(W * H, 0xFF4080C0, np.uint32)
+    pc = oracle.OracleParams(width=W, height=H, chroma_a=2, chroma_b=0, factor=4)
+    assert len(np.unique(oracle.process(pc, const, "avg"))) == 1
