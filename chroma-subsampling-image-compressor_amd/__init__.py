@@ -6,7 +6,7 @@ include/csic.h; this package is the host-side mirror of the reference's generato
 ImageCompressionApp).  There is no CPU compute path in here.
 """
 from . import _native
-from ._native import CsicRuntimeError, IllegalArgumentException
+from ._native import CsicIOError, CsicRuntimeError, IllegalArgumentException
 from .params import ImageProcessorParams, PixelFormat, ProcessingStep, Rounding, Sampling, make_c_params
 from .compressor import ImageCompressorTop, ImageProcessor, Plan
 from .model import Image, ImageProcessorModel
@@ -16,7 +16,7 @@ from .distributed import Stripe, StripedImageCompressorTop, stripe_for_rank
 from . import app, compressor, distributed, model, params, pipeline
 
 __all__ = [
-    "CsicRuntimeError", "IllegalArgumentException", "ImageProcessorParams", "PixelFormat", "ProcessingStep",
+    "CsicIOError", "CsicRuntimeError", "IllegalArgumentException", "ImageProcessorParams", "PixelFormat", "ProcessingStep",
     "Rounding", "Sampling", "make_c_params", "ImageCompressorTop", "ImageProcessor", "Plan", "Image", "ImageProcessorModel",
     "ImageCompressionApp", "FramePipeline", "Stripe", "StripedImageCompressorTop", "stripe_for_rank",
 ]

@@ -14,6 +14,7 @@ EINVAL_NULL, EINVAL_DIMS, EINVAL_FACTOR, EINVAL_CHROMA_A, EINVAL_CHROMA_B = -1, 
 EINVAL_BITS, EINVAL_OP_PERMUTATION, EINVAL_ROUNDING, EINVAL_FORMAT = -6, -7, -8, -9
 EINVAL_NOT_DIVISIBLE, EINVAL_SAMPLING, EINVAL_STRIPE, EINVAL_SIZE = -10, -11, -12, -13
 ENODEVICE, EHIP, ENOMEM = -20, -21, -22
+EIO, EFORMAT = -30, -31
 
 OP_NOOP, OP_SPATIAL, OP_QUANT, OP_CHROMA = 0, 1, 2, 3
 ROUND_FLOOR_HW, ROUND_TRUNC_SW = 0, 1
@@ -33,6 +34,14 @@ class IllegalArgumentException(ValueError):
 
 class CsicRuntimeError(RuntimeError):
     """HIP / device failures (CSIC_ENODEVICE, CSIC_EHIP, CSIC_ENOMEM)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+class CsicIOError(OSError):
+    """CSIC_EIO / CSIC_EFORMAT from the PNG codec."""
 
     def __init__(self, status: int, message: str):
         super().__init__(message)
@@ -73,6 +82,9 @@ PROTOTYPES = {
     "csic_process_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "csic_synth_frame_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]),
     "csic_checksum_device": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64), C.c_void_p]),
+    "csic_png_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "csic_png_read_argb": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t]),
+    "csic_png_write_argb": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "csic_pipeline_create": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "csic_pipeline_destroy": (C.c_int, [C.c_void_p]),
     "csic_pipeline_acquire_input": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32))]),
@@ -117,4 +129,6 @@ def check(status: int) -> int:
     msg = lib().csic_last_error().decode() or lib().csic_strerror(status).decode()
     if EINVAL_SIZE <= status <= EINVAL_NULL:
         raise IllegalArgumentException(status, "requirement failed: " + msg)
+    if status in (EIO, EFORMAT):
+        raise CsicIOError(status, msg)
     raise CsicRuntimeError(status, msg)

@@ -61,8 +61,8 @@ class ImageCompressionApp:
         pinned staging, and H2D / kernel / D2H of neighbouring images overlap.  Output files are what
         processImage would write for each input."""
         from .pipeline import FramePipeline
-        first = ImageProcessorModel.readImage(inputImagePaths[0])
-        W, H, f = first.width, first.height, spatialFactorToUse
+        W, H = ImageProcessorModel.imageSize(inputImagePaths[0])
+        f = spatialFactorToUse
         top = ImageCompressorTop(W, H, chromaParamA, chromaParamB, yTargetBits, cbTargetBits, crTargetBits,
                                  f, op1, op2, op3, device=device)
         finalW, finalH = W // f, H // f
@@ -76,14 +76,11 @@ class ImageCompressionApp:
 
         with FramePipeline(top.plan(), depth) as pipe:
             done = 0
-            for k, path in enumerate(inputImagePaths):
-                img = first if k == 0 else ImageProcessorModel.readImage(path)
-                if (img.width, img.height) != (W, H):
-                    raise N.IllegalArgumentException(N.EINVAL_SIZE, f"requirement failed: {path} is {img.width}x{img.height}, "
-                                                     f"expected {W}x{H}")
+            for path in inputImagePaths:
                 if pipe.pending == depth:
                     write(pipe.collect()[1], todo[done]); done += 1
-                np.copyto(pipe.acquire_input(), img.argb)
+                # decode straight into the pinned staging buffer (a size mismatch raises IllegalArgumentException)
+                ImageProcessorModel.readImageInto(path, pipe.acquire_input())
                 pipe.submit()
             while pipe.pending:
                 write(pipe.collect()[1], todo[done]); done += 1

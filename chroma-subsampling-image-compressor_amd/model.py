@@ -6,9 +6,10 @@ ImageProcessorModel <- object ImageProcessorModel, src/test/scala/jpeg/ImageProc
   writeImage(pixels, params, file)     :24-28
   getImageParams(image, n)             :33-41   ImageProcessorParams(w, h, factor = n, 4, 4)
   getImagePixels(image)                :43-52   [row][col] -> (r, g, b)
-The reference object holds no arithmetic; neither does this one.  PNG coding uses Pillow (the reference
-uses scrimage 4.1.1; decoding is pinned as equivalent by the golden images, SURVEY.md 8c: plain 8-bit
-samples, alpha ignored on input, gAMA/cHRM not applied).
+The reference object holds no arithmetic; neither does this one.  PNG coding is the library's own codec
+(csic_png_* in include/csic.h, zlib only; the reference uses scrimage 4.1.1 -- decoding is pinned as
+equivalent by the golden images, SURVEY.md 8c: plain 8-bit samples, alpha ignored on input, gAMA/cHRM
+not applied).
 """
 from __future__ import annotations
 
@@ -18,6 +19,9 @@ from typing import List, Sequence
 
 import numpy as np
 
+import ctypes as C
+
+from . import _native as N
 from .params import ImageProcessorParams
 
 PixelType = Sequence[int]             # ImageProcessorModel.scala:11
@@ -55,16 +59,30 @@ class Image:
 
 class ImageProcessorModel:
     @staticmethod
-    def readImage(file: str) -> Image:
-        from PIL import Image as PILImage
-        with PILImage.open(file) as im:
-            return Image.from_rgb(np.asarray(im.convert("RGB"), dtype=np.uint8))
+    def imageSize(file: str):
+        w, h = C.c_int32(), C.c_int32()
+        N.check(N.lib().csic_png_info(os.fsencode(file), C.byref(w), C.byref(h)))
+        return w.value, h.value
 
     @staticmethod
-    def writeImage(image, file_or_params, file: str = None) -> None:
+    def readImage(file: str) -> Image:
+        w, h = ImageProcessorModel.imageSize(file)
+        argb = np.empty((h, w), dtype=np.uint32)
+        ImageProcessorModel.readImageInto(file, argb)
+        return Image(argb)
+
+    @staticmethod
+    def readImageInto(file: str, dst: np.ndarray) -> None:
+        """Decodes straight into `dst` (uint32, C-contiguous, H*W elements) -- e.g. the pinned staging view
+        returned by FramePipeline.acquire_input()."""
+        if dst.dtype != np.uint32 or not dst.flags["C_CONTIGUOUS"]:
+            raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: dst must be C-contiguous uint32")
+        N.check(N.lib().csic_png_read_argb(os.fsencode(file), dst.ctypes.data_as(C.c_void_p), dst.size))
+
+    @staticmethod
+    def writeImage(image, file_or_params, file: str = None, compression: int = 6) -> None:
         """writeImage(image, file) or writeImage(pixels, params, file) -- both overloads of
         ImageProcessorModel.scala:18-28."""
-        from PIL import Image as PILImage
         if file is None:
             img, path = image, file_or_params
         else:
@@ -72,8 +90,10 @@ class ImageProcessorModel:
             img = Image(np.asarray(image, dtype=np.uint32).reshape(p.height, p.width))
             path = file
         parent = os.path.dirname(os.path.abspath(path))
-        os.makedirs(parent, exist_ok=True)
-        PILImage.fromarray(img.rgb(), "RGB").save(path, format="PNG")
+        os.makedirs(parent, exist_ok=True)                     # outputFile.getParentFile().mkdirs(), :20
+        argb = np.ascontiguousarray(img.argb, dtype=np.uint32)
+        N.check(N.lib().csic_png_write_argb(os.fsencode(path), argb.ctypes.data_as(C.c_void_p), img.width, img.height,
+                                            compression))
 
     @staticmethod
     def getImageParams(image: Image, numPixelsPerCycle: int) -> ImageProcessorParams:

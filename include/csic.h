@@ -56,7 +56,9 @@ typedef enum csic_status {
     CSIC_EINVAL_SIZE            = -13, /* buffer size does not match the plan                          */
     CSIC_ENODEVICE              = -20, /* no HIP device / bad device ordinal                           */
     CSIC_EHIP                   = -21, /* a HIP runtime call failed (message has the HIP error string) */
-    CSIC_ENOMEM                 = -22
+    CSIC_ENOMEM                 = -22,
+    CSIC_EIO                    = -30, /* file cannot be opened / read / written                       */
+    CSIC_EFORMAT                = -31  /* not a PNG, corrupt, or an unsupported PNG feature            */
 } csic_status;
 
 /* ---- enumerations -------------------------------------------------------------------------------*/
@@ -189,6 +191,17 @@ int  csic_synth_frame_device(void *d_dst, int64_t npix, int64_t first_index, uin
 /* 64-bit order-sensitive checksum of npix pixels in device memory (sum of fmix32-mixed
  * (pixel, index) pairs), for the full-size parity properties; synchronous. */
 int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *hip_stream);
+
+/* ---- PNG files (host only, zlib) --------------------------------------------------------------------
+ * The codec either side of the path: stands in for scrimage's loader / PngWriter behind
+ * ImageProcessorModel.readImage / writeImage (ImageProcessorModel.scala:14-22).  Decoding yields straight
+ * 8-bit samples as ARGB ints with alpha = 255 (input alpha dropped, gAMA/cHRM not applied -- the behaviour
+ * the reference's golden images pin) and writes directly into `dst`, which may be a pinned
+ * buffer from csic_pipeline_acquire_input.  Non-interlaced PNGs of every colour type / bit depth are read;
+ * 8-bit RGB is written (`level` = zlib level 0..9). */
+int  csic_png_info(const char *path, int32_t *width, int32_t *height);
+int  csic_png_read_argb(const char *path, uint32_t *dst, size_t dst_px);
+int  csic_png_write_argb(const char *path, const uint32_t *src, int32_t width, int32_t height, int32_t level);
 
 /* ---- host-frame pipeline (the step either side of the hot path) -----------------------------------
  * Replaces the reference's per-image  readImage -> per-pixel poke ... peek -> writeImage  flow

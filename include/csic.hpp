@@ -34,7 +34,7 @@ inline int check(int status)
     std::string msg = csic_last_error();
     if (msg.empty()) msg = csic_strerror(status);
     if (status <= CSIC_EINVAL_NULL && status >= CSIC_EINVAL_SIZE) throw IllegalArgumentException(status, msg);
-    throw RuntimeError(status, msg);
+    throw RuntimeError(status, msg);   // device, memory and file errors
 }
 
 enum class ProcessingStep : int32_t { NoOp = 0, SpatialSampling = 1, ColorQuantization = 2, ChromaSubsampling = 3 };
@@ -56,6 +56,34 @@ struct ImageProcessorParams {
         p.chroma_a = chromaParamA; p.chroma_b = chromaParamB; p.factor = factor;
         p.rounding = (int32_t)r; p.out_format = (int32_t)f; p.strict_divisible = 1;
         return p;
+    }
+};
+
+// Stand-in for scrimage's image objects: width, height, packed ARGB ints (0xAARRGGBB).
+struct Image {
+    int width = 0, height = 0;
+    std::vector<uint32_t> argb;
+};
+
+// object ImageProcessorModel, src/test/scala/jpeg/ImageProcessorModel.scala:9-53 -- I/O helpers, no arithmetic.
+struct ImageProcessorModel {
+    static Image readImage(const std::string &file)                                  // :14-16
+    {
+        Image im;
+        int32_t w = 0, h = 0;
+        check(csic_png_info(file.c_str(), &w, &h));
+        im.width = w; im.height = h;
+        im.argb.resize((size_t)w * h);
+        check(csic_png_read_argb(file.c_str(), im.argb.data(), im.argb.size()));
+        return im;
+    }
+    static void writeImage(const Image &im, const std::string &file, int compression = 6)   // :18-22
+    {
+        check(csic_png_write_argb(file.c_str(), im.argb.data(), im.width, im.height, compression));
+    }
+    static ImageProcessorParams getImageParams(const Image &im, int numPixelsPerCycle)      // :33-41
+    {
+        return ImageProcessorParams(im.width, im.height, numPixelsPerCycle, 4, 4);
     }
 };
 

@@ -84,10 +84,41 @@ static void gpu_checks()
     }
 }
 
+// SpatialDownsamplerSpec.scala:155-230 in C++: in16x16.png -> ImageProcessorParams(w, h, 2, 2, 0) ->
+// ImageProcessor -> 8x8, pixels pinned by APP_OUTPUT/spatial_downsampler_integration_420_sf2.png
+static void integration_flow(const char *in_png, const char *golden_png, const char *out_png)
+{
+    const Image in = ImageProcessorModel::readImage(in_png);
+    EXPECT(in.width == 16 && in.height == 16);
+    ImageProcessor dut(ImageProcessorParams(in.width, in.height, 2, 2, 0));
+    Image out;
+    out.width = dut.outWidth(); out.height = dut.outHeight();
+    out.argb = dut.process(in.argb);
+    ImageProcessorModel::writeImage(out, out_png);
+    const Image back = ImageProcessorModel::readImage(out_png), want = ImageProcessorModel::readImage(golden_png);
+    EXPECT(back.width == 8 && back.height == 8 && back.argb == want.argb);
+}
+
+static void png_checks(const char *in_png)
+{
+    const Image im = ImageProcessorModel::readImage(in_png);
+    EXPECT(im.width == 16 && im.height == 16 && im.argb.size() == 256);
+    EXPECT((im.argb[0] >> 24) == 0xFF);
+    const ImageProcessorParams p = ImageProcessorModel::getImageParams(im, 1);
+    EXPECT(p.factor == 1 && p.chromaParamA == 4 && p.chromaParamB == 4);
+    bool io = false;
+    try { ImageProcessorModel::readImage("/nonexistent/x.png"); } catch (const RuntimeError &e) { io = e.status == CSIC_EIO; }
+    EXPECT(io);
+}
+
 int main(int argc, char **argv)
 {
     cpu_checks();
-    if (argc > 1 && std::strcmp(argv[1], "gpu") == 0) gpu_checks();
+    if (argc > 2) png_checks(argv[2]);
+    if (argc > 1 && std::strcmp(argv[1], "gpu") == 0) {
+        gpu_checks();
+        if (argc > 4) integration_flow(argv[2], argv[3], argv[4]);
+    }
     std::printf(fails ? "%d check(s) failed\n" : "all checks passed\n", fails);
     return fails ? 1 : 0;
 }

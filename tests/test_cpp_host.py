@@ -23,15 +23,18 @@ def _build():
     return EXE
 
 
-def _run(mode):
-    r = subprocess.run([_build(), mode], capture_output=True, text=True, timeout=120)
+def _run(mode, tmp_path):
+    golden = os.path.join(ROOT, "tests", "golden")
+    args = [_build(), mode, os.path.join(golden, "inputs", "in16.png"),
+            os.path.join(golden, "outputs", "ip_420_sf2_16.png"), str(tmp_path / "cpp_out.png")]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
 
 
-def test_cpp_host_layer_requires():
-    _run("cpu")
+def test_cpp_host_layer_requires_and_png(tmp_path):
+    _run("cpu", tmp_path)
 
 
 @pytest.mark.gpu
-def test_cpp_host_layer_kats_on_gpu():
-    _run("gpu")
+def test_cpp_host_layer_kats_and_integration_flow_on_gpu(tmp_path):
+    _run("gpu", tmp_path)

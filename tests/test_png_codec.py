@@ -1,0 +1,120 @@
+"""The library's PNG codec (csic_png_*) against Pillow as an independent decoder/encoder, on the reference's
+own PNG files (3 inputs + 29 outputs: RGB, RGBA, with and without gAMA/cHRM) and on synthetic files covering
+every filter type, colour type and bit depth."""
+import glob
+import os
+
+import numpy as np
+import pytest
+from PIL import Image as PILImage
+
+from conftest import GOLDEN, load_png_rgb
+
+import csic_amd as csic
+
+M = csic.ImageProcessorModel
+FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "inputs", "*.png")) + glob.glob(os.path.join(GOLDEN, "outputs", "*.png")))
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p) for p in FIXTURES])
+def test_decodes_reference_files_like_pillow(path):
+    img = M.readImage(path)
+    want = load_png_rgb(path)
+    assert (img.height, img.width) == want.shape[:2]
+    assert np.array_equal(img.rgb(), want)
+    assert np.all((img.argb >> 24) == 0xFF)                       # alpha dropped on input, 255 out
+
+
+def test_roundtrip_and_pillow_reads_our_files(tmp_path):
+    rng = np.random.default_rng(1)
+    for k, (W, H) in enumerate([(1, 1), (3, 5), (64, 48), (257, 31)]):
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        if k == 2:
+            rgb[:, :, :] = np.linspace(0, 255, W, dtype=np.uint8)[None, :, None]     # smooth: exercises Sub/Paeth choices
+        p = tmp_path / f"rt{k}.png"
+        for level in (0, 6, 9):
+            M.writeImage(csic.Image.from_rgb(rgb), str(p), compression=level)
+            assert np.array_equal(M.readImage(str(p)).rgb(), rgb)
+            assert np.array_equal(np.asarray(PILImage.open(p).convert("RGB")), rgb)
+            assert PILImage.open(p).mode == "RGB"                  # like BufferedImage.TYPE_INT_RGB dumps
+
+
+@pytest.mark.parametrize("mode", ["L", "LA", "P", "RGB", "RGBA", "1"])
+def test_decodes_every_colour_type(tmp_path, mode):
+    rng = np.random.default_rng(2)
+    rgb = rng.integers(0, 256, (33, 47, 3), dtype=np.uint8)
+    im = PILImage.fromarray(rgb, "RGB").convert(mode)
+    p = tmp_path / f"{mode}.png"
+    im.save(p)
+    assert np.array_equal(M.readImage(str(p)).rgb(), np.asarray(PILImage.open(p).convert("RGB")))
+
+
+def test_low_bit_depths_and_16_bit(tmp_path):
+    rng = np.random.default_rng(3)
+    for bits in (1, 2, 4):                                         # palette images with sub-byte indices
+        idx = rng.integers(0, 1 << bits, (19, 23), dtype=np.uint8)
+        im = PILImage.fromarray(idx, "P")
+        im.putpalette([int(v) for v in rng.integers(0, 256, 3 << bits)])
+        p = tmp_path / f"p{bits}.png"
+        im.save(p, bits=bits)
+        assert np.array_equal(M.readImage(str(p)).rgb(), np.asarray(PILImage.open(p).convert("RGB")))
+    g16 = rng.integers(0, 65536, (9, 13), dtype=np.uint16)
+    p = tmp_path / "g16.png"
+    PILImage.fromarray(g16, "I;16").save(p)
+    got = M.readImage(str(p)).rgb()
+    assert np.array_equal(got[..., 0], (g16 >> 8).astype(np.uint8)) and np.array_equal(got[..., 0], got[..., 2])
+
+
+def test_all_filter_types_are_unfiltered(tmp_path):
+    """Hand-built PNGs that force each of the five row filters."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(4)
+    W, H = 21, 11
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    for ft in range(5):
+        raw = bytearray()
+        prev = np.zeros(W * 3, np.int32)
+        for y in range(H):
+            cur = rgb[y].reshape(-1).astype(np.int32)
+            a = np.concatenate([np.zeros(3, np.int32), cur[:-3]])
+            c = np.concatenate([np.zeros(3, np.int32), prev[:-3]])
+            if ft == 0: pred = np.zeros_like(cur)
+            elif ft == 1: pred = a
+            elif ft == 2: pred = prev
+            elif ft == 3: pred = (a + prev) >> 1
+            else:
+                pp = a + prev - c
+                pa, pb, pc = np.abs(pp - a), np.abs(pp - prev), np.abs(pp - c)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+            raw.append(ft)
+            raw += bytes(((cur - pred) & 0xFF).astype(np.uint8))
+            prev = cur
+
+        def chunk(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+        data = (bytes([0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A]) + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+        p = tmp_path / f"f{ft}.png"
+        p.write_bytes(data)
+        assert np.array_equal(np.asarray(PILImage.open(p).convert("RGB")), rgb)      # the file is valid
+        assert np.array_equal(M.readImage(str(p)).rgb(), rgb), ft
+
+
+def test_error_paths(tmp_path):
+    with pytest.raises(csic.CsicIOError) as ei:
+        M.readImage(str(tmp_path / "missing.png"))
+    assert ei.value.status == csic._native.EIO
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(b"not a png at all, sorry" * 4)
+    with pytest.raises(csic.CsicIOError) as ei:
+        M.readImage(str(bad))
+    assert ei.value.status == csic._native.EFORMAT
+    good = os.path.join(GOLDEN, "inputs", "in16.png")
+    data = bytearray(open(good, "rb").read())
+    data[60] ^= 0xFF                                               # flip a bit inside a chunk: CRC must catch it
+    (tmp_path / "crc.png").write_bytes(bytes(data))
+    with pytest.raises(csic.CsicIOError):
+        M.readImage(str(tmp_path / "crc.png"))
+    with pytest.raises(csic.IllegalArgumentException):            # destination of the wrong size
+        M.readImageInto(good, np.empty(17, np.uint32))
