@@ -196,6 +196,25 @@ __global__ void __launch_bounds__(256) k_e10(KArgs a, int row_mul)
     for (int k = 0; k < K; ++k) st1<true>(op + co0 + k * 256, pix<true>(px[k], a));
 }
 
+// E11: decimation by F with K loads per lane; LW = load width in dwords (1 or 4; only element 0 is used)
+template <int F, int K, int LW, bool NTL, bool NTS>
+__global__ void __launch_bounds__(256) k_e11(KArgs a)
+{
+    const int co0 = blockIdx.x * (256 * K) + threadIdx.x;
+    const int ro = blockIdx.y;
+    const uint32_t *rp = a.in + (int64_t)(ro * F) * a.W;
+    uint32_t *op = a.out + (int64_t)ro * a.Wo;
+    uint32_t px[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int co = co0 + k * 256;
+        if (LW == 4) { const u32x4 v = ld4<NTL>(rp + co * F); px[k] = v.x ^ (v.w & 0u); asm volatile("" ::"v"(v.y), "v"(v.z), "v"(v.w)); }
+        else px[k] = ld1<NTL>(rp + co * F);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) st1<NTS>(op + co0 + k * 256, pix<true>(px[k], a));
+}
+
 struct Bench {
     int W = 8192, H = 8192, Wo = 4096, Ho = 4096;
     int nring = 6, iters = 60;
@@ -318,5 +337,27 @@ int main()
     B.run("E10 K4 rows skipped (x2) grid 4x4096", [&](int i) { hipLaunchKernelGGL((k_e10<4>), dim3(4, 4096), dim3(256), 0, 0, B.args(i), 2); });
     B.run("E10 K4 rows contiguous   grid 4x4096", [&](int i) { hipLaunchKernelGGL((k_e10<4>), dim3(4, 4096), dim3(256), 0, 0, B.args(i), 1); });
     for (int i = 0; i < B.nring; ++i) hipLaunchKernelGGL(k_synth, dim3(8192), dim3(256), 0, 0, B.in[i], (int64_t)B.W * B.H, (int64_t)i * B.W * B.H, 20250629u * 0x9E3779B9u);
+
+    {   // f = 8 on 8192x8192: Wo = Ho = 1024; algorithmic bytes = 4*8192*1024 + 4*1024*1024
+        KArgs proto = B.base; proto.Wo = 1024; proto.Ho = 1024; proto.f = 8;
+        auto a8 = [&](int i) { KArgs a = proto; a.in = B.in[i]; a.out = B.out[i]; return a; };
+        const double by8 = 4.0 * 8192 * 1024 + 4.0 * 1024 * 1024;
+        B.run("E11 f8 K1 dword nt   grid 4x1024", [&](int i) { hipLaunchKernelGGL((k_e11<8, 1, 1, true, true>), dim3(4, 1024), dim3(256), 0, 0, a8(i)); }, by8);
+        B.run("E11 f8 K2 dword nt   grid 2x1024", [&](int i) { hipLaunchKernelGGL((k_e11<8, 2, 1, true, true>), dim3(2, 1024), dim3(256), 0, 0, a8(i)); }, by8);
+        B.run("E11 f8 K4 dword nt   grid 1x1024", [&](int i) { hipLaunchKernelGGL((k_e11<8, 4, 1, true, true>), dim3(1, 1024), dim3(256), 0, 0, a8(i)); }, by8);
+        B.run("E11 f8 K1 dword cached grid 4x1024", [&](int i) { hipLaunchKernelGGL((k_e11<8, 1, 1, false, true>), dim3(4, 1024), dim3(256), 0, 0, a8(i)); }, by8);
+        B.run("E11 f8 K4 dword cached grid 1x1024", [&](int i) { hipLaunchKernelGGL((k_e11<8, 4, 1, false, true>), dim3(1, 1024), dim3(256), 0, 0, a8(i)); }, by8);
+        B.run("E11 f8 K1 x4 nt      grid 4x1024", [&](int i) { hipLaunchKernelGGL((k_e11<8, 1, 4, true, true>), dim3(4, 1024), dim3(256), 0, 0, a8(i)); }, by8);
+        B.run("E11 f8 K4 x4 nt      grid 1x1024", [&](int i) { hipLaunchKernelGGL((k_e11<8, 4, 4, true, true>), dim3(1, 1024), dim3(256), 0, 0, a8(i)); }, by8);
+        B.run("E11 f8 K2 x4 cached  grid 2x1024", [&](int i) { hipLaunchKernelGGL((k_e11<8, 2, 4, false, true>), dim3(2, 1024), dim3(256), 0, 0, a8(i)); }, by8);
+        KArgs p4 = B.base; p4.Wo = 2048; p4.Ho = 2048; p4.f = 4;
+        auto a4 = [&](int i) { KArgs a = p4; a.in = B.in[i]; a.out = B.out[i]; return a; };
+        const double by4 = 4.0 * 8192 * 2048 + 4.0 * 2048 * 2048;
+        B.run("E11 f4 K4 dword nt   grid 2x2048", [&](int i) { hipLaunchKernelGGL((k_e11<4, 4, 1, true, true>), dim3(2, 2048), dim3(256), 0, 0, a4(i)); }, by4);
+        B.run("E11 f4 K2 dword nt   grid 4x2048", [&](int i) { hipLaunchKernelGGL((k_e11<4, 2, 1, true, true>), dim3(4, 2048), dim3(256), 0, 0, a4(i)); }, by4);
+        B.run("E11 f4 K1 dword nt   grid 8x2048", [&](int i) { hipLaunchKernelGGL((k_e11<4, 1, 1, true, true>), dim3(8, 2048), dim3(256), 0, 0, a4(i)); }, by4);
+        B.run("E11 f4 K2 x4 nt      grid 4x2048", [&](int i) { hipLaunchKernelGGL((k_e11<4, 2, 4, true, true>), dim3(4, 2048), dim3(256), 0, 0, a4(i)); }, by4);
+        B.run("E11 f4 K4 dword cached grid 2x2048", [&](int i) { hipLaunchKernelGGL((k_e11<4, 4, 1, false, true>), dim3(2, 2048), dim3(256), 0, 0, a4(i)); }, by4);
+    }
     return 0;
 }
