@@ -11,12 +11,15 @@ from .params import ImageProcessorParams, PixelFormat, ProcessingStep, Rounding,
 from .compressor import ImageCompressorTop, ImageProcessor, Plan
 from .model import Image, ImageProcessorModel
 from .pipeline import FramePipeline
+from .stages import (ChromaSubsampler, ColorQuantizer, ReferenceModel, RGB2YCbCr, SpatialDownsampler, YCbCrUtils,
+                     pack_ycc, unpack_ycc)
 from .app import ImageCompressionApp
 from .distributed import Stripe, StripedImageCompressorTop, stripe_for_rank
-from . import app, compressor, distributed, model, params, pipeline
+from . import app, compressor, distributed, model, params, pipeline, stages
 
 __all__ = [
     "CsicIOError", "CsicRuntimeError", "IllegalArgumentException", "ImageProcessorParams", "PixelFormat", "ProcessingStep",
     "Rounding", "Sampling", "make_c_params", "ImageCompressorTop", "ImageProcessor", "Plan", "Image", "ImageProcessorModel",
-    "ImageCompressionApp", "FramePipeline", "Stripe", "StripedImageCompressorTop", "stripe_for_rank",
+    "ImageCompressionApp", "FramePipeline", "ChromaSubsampler", "ColorQuantizer", "ReferenceModel", "RGB2YCbCr",
+    "SpatialDownsampler", "YCbCrUtils", "pack_ycc", "unpack_ycc", "Stripe", "StripedImageCompressorTop", "stripe_for_rank",
 ]

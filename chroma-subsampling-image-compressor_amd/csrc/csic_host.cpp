@@ -66,8 +66,8 @@ static int validate_impl(const csic_params *p)
     if (p->sampling == CSIC_SAMPLING_AVG &&
         !(p->op[0] == CSIC_OP_CHROMA && p->op[1] == CSIC_OP_SPATIAL && p->op[2] == CSIC_OP_QUANT))
         return set_error(CSIC_EINVAL_SAMPLING, "the AVG extension is defined for the order chroma -> spatial -> quant only");
-    if (p->in_format != CSIC_FMT_ARGB8888)
-        return set_error(CSIC_EINVAL_FORMAT, "in_format must be ARGB8888(0). Got %d", p->in_format);
+    if (p->in_format != CSIC_FMT_ARGB8888 && p->in_format != CSIC_FMT_YCBCR888X)
+        return set_error(CSIC_EINVAL_FORMAT, "in_format must be ARGB8888(0) or YCBCR888X(1). Got %d", p->in_format);
     if (p->out_format != CSIC_FMT_ARGB8888 && p->out_format != CSIC_FMT_YCBCR888X)
         return set_error(CSIC_EINVAL_FORMAT, "out_format must be ARGB8888(0) or YCBCR888X(1). Got %d", p->out_format);
     // ImageProcessor.scala:25 -- a rule of ImageProcessorParams only; the raw RTL accepts any size

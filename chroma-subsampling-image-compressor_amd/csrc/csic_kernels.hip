@@ -120,6 +120,16 @@ __device__ __forceinline__ void fwd_c(uint32_t px, uint32_t &cb, uint32_t &cr)
     }
 }
 
+// (Y, Cb, Cr) of an input pixel: the forward transform, or plain unpacking for a YCbCr input stream
+template <int ROUND, int INFMT>
+__device__ __forceinline__ uint32_t in_y(uint32_t px) { return INFMT == F_YCC ? (px & 0xFFu) : fwd_y(px); }
+template <int ROUND, int INFMT>
+__device__ __forceinline__ void in_c(uint32_t px, uint32_t &cb, uint32_t &cr)
+{
+    if (INFMT == F_YCC) { cb = (px >> 8) & 0xFFu; cr = (px >> 16) & 0xFFu; }
+    else fwd_c<ROUND>(px, cb, cr);
+}
+
 // Chroma-dependent part of the inverse transform, shared by all pixels that hold the same chroma.
 //   R = clamp((298Y + 409(Cr-128) + 128) >> 8)                 = clamp((298Y + KR) >> 8)
 //   G = clamp((298Y - 100(Cb-128) - 208(Cr-128) + 128) >> 8)   = clamp((298Y + KG) >> 8)
@@ -458,7 +468,7 @@ __global__ void __launch_bounds__(256) k_avg(KArgs a)
 }
 
 // Any shape: one output pixel per lane, clamped coordinates, orc_process_avg verbatim.
-template <int ROUND, int FMT>
+template <int ROUND, int FMT, int INFMT>
 __global__ void __launch_bounds__(256) k_avg_generic(KArgs a)
 {
     pin_args(a);
@@ -474,14 +484,14 @@ __global__ void __launch_bounds__(256) k_avg_generic(KArgs a)
         for (int i = 0; i < f; ++i) {
             for (int j = 0; j < f; ++j) {
                 const int r = min(ro * f + i, a.H - 1), c = min(co * f + j, a.W - 1);
-                sy += fwd_y(in[(int64_t)r * a.W + c]);
+                sy += in_y<ROUND, INFMT>(in[(int64_t)r * a.W + c]);
                 const int r0 = r & ~a.vmask, c0 = c & ~a.hmask;
                 uint32_t ab = 0, ar = 0;
                 for (int ii = 0; ii < v; ++ii) {
                     for (int jj = 0; jj < h; ++jj) {
                         const int rr = min(r0 + ii, a.H - 1), cc = min(c0 + jj, a.W - 1);
                         uint32_t cb, cr;
-                        fwd_c<ROUND>(in[(int64_t)rr * a.W + cc], cb, cr);
+                        in_c<ROUND, INFMT>(in[(int64_t)rr * a.W + cc], cb, cr);
                         ab += cb; ar += cr;
                     }
                 }
@@ -499,7 +509,7 @@ __global__ void __launch_bounds__(256) k_avg_generic(KArgs a)
 // ------------------------------------------------------------------------------------------------
 // k_generic: any parameters, one output pixel per lane (SURVEY.md App. A.3 / A.4 verbatim)
 // ------------------------------------------------------------------------------------------------
-template <int ROUND, int FMT>
+template <int ROUND, int FMT, int INFMT>
 __global__ void __launch_bounds__(256) k_generic(KArgs a)
 {
     pin_args(a);
@@ -524,8 +534,10 @@ __global__ void __launch_bounds__(256) k_generic(KArgs a)
             const int sro = src / a.Wo, sco = src - sro * a.Wo;
             c_idx = (int64_t)(sro * a.f) * a.W + sco * a.f;
         }
-        const ChromaTerm t = chroma_term<ROUND, FMT>(in[c_idx], a.mcb, a.mcr);
-        out[(int64_t)ro * a.Wo + co] = finish<FMT>(in[y_idx], a.my, t);
+        uint32_t cb, cr;
+        in_c<ROUND, INFMT>(in[c_idx], cb, cr);
+        const uint32_t y = in_y<ROUND, INFMT>(in[y_idx]) & a.my;
+        out[(int64_t)ro * a.Wo + co] = finish_y<FMT>(y, chroma_term_q<FMT>(cb & a.mcb, cr & a.mcr));
     }
 }
 
@@ -672,10 +684,13 @@ static void select_rf(csic_plan *pl)
     const char *fn = FMT == F_ARGB ? "argb" : "ycc";
     const bool nt = !pl->no_nt;
     const char *ntn = nt ? "nt" : "cached";
+    // A YCbCr input stream (single-stage driving, the reference's spec style) is a test-oriented path:
+    // it is served by the run-time-parameter kernels only.
+    const bool ycc_in = pl->p.in_format == CSIC_FMT_YCBCR888X;
     if (pl->p.sampling == CSIC_SAMPLING_AVG) {
         const int th = g.f > g.v ? g.f : g.v;
         const int tw = g.f == 8 ? 8 : 4;
-        if (!pl->force_generic && !pl->no_vec && g.W % tw == 0 && g.H % th == 0) {
+        if (!pl->force_generic && !ycc_in && !pl->no_vec && g.W % tw == 0 && g.H % th == 0) {
             pl->fam = FAM_AVG;
             pl->fn = nt ? pick_avg<ROUND, FMT, true>(g.f, g.h, g.v) : pick_avg<ROUND, FMT, false>(g.f, g.h, g.v);
             pl->units_per_row = g.W / 4;
@@ -683,23 +698,23 @@ static void select_rf(csic_plan *pl)
             snprintf(pl->name, sizeof pl->name, "k_avg<%s,%s,f%d,h%d,v%d,%s>", rn, fn, g.f, g.h, g.v, ntn);
         } else {
             pl->fam = FAM_AVG_GENERIC;
-            pl->fn = k_avg_generic<ROUND, FMT>;
+            pl->fn = ycc_in ? (KernelFn)k_avg_generic<ROUND, FMT, F_YCC> : (KernelFn)k_avg_generic<ROUND, FMT, F_ARGB>;
             pl->units_per_row = g.Wo;
             pl->k_per_lane = 1;
-            snprintf(pl->name, sizeof pl->name, "k_avg_generic<%s,%s>", rn, fn);
+            snprintf(pl->name, sizeof pl->name, "k_avg_generic<%s,%s%s>", rn, fn, ycc_in ? ",ycc-in" : "");
         }
         return;
     }
     // f = 1: the 16-byte kernel wins for v = 1 (8192^2 4:4:4: 84.1 vs 88.0 us); for 4:x:0 the 4-byte k_dec<f1>
     // with its per-row broadcast wins (86.2 vs 89-91 us), unless the frame is too narrow for it.
-    const bool f1x4_ok = !pl->force_generic && !pl->no_vec && g.f == 1 && g.W % 4 == 0;
+    const bool f1x4_ok = !pl->force_generic && !ycc_in && !pl->no_vec && g.f == 1 && g.W % 4 == 0;
     if (f1x4_ok && (g.v == 1 || pl->variant == 3 || !dec_fast_ok(g))) {
         pl->fam = FAM_F1X4;
         pl->fn = nt ? pick_f1x4<ROUND, FMT, true>(g.h, g.v) : pick_f1x4<ROUND, FMT, false>(g.h, g.v);
         pl->units_per_row = g.W / 4;
         pl->k_per_lane = 1;
         snprintf(pl->name, sizeof pl->name, "k_f1x4<%s,%s,h%d,v%d,%s>", rn, fn, g.h, g.v, ntn);
-    } else if (!pl->force_generic && dec_fast_ok(g)) {
+    } else if (!pl->force_generic && !ycc_in && dec_fast_ok(g)) {
         // in-row chroma hold distance in decimated lanes; srows = chroma rows follow the decimated stream
         // (with f = 1 the decimated stream IS the image and both order classes coincide: any width, any
         // 4-byte-aligned pointer, 4-byte accesses)
@@ -723,10 +738,10 @@ static void select_rf(csic_plan *pl)
         }
     } else {
         pl->fam = FAM_GENERIC;
-        pl->fn = k_generic<ROUND, FMT>;
+        pl->fn = ycc_in ? (KernelFn)k_generic<ROUND, FMT, F_YCC> : (KernelFn)k_generic<ROUND, FMT, F_ARGB>;
         pl->units_per_row = g.Wo;
         pl->k_per_lane = 1;
-        snprintf(pl->name, sizeof pl->name, "k_generic<%s,%s>", rn, fn);
+        snprintf(pl->name, sizeof pl->name, "k_generic<%s,%s%s>", rn, fn, ycc_in ? ",ycc-in" : "");
     }
 }
 

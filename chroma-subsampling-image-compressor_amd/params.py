@@ -49,7 +49,7 @@ class PixelFormat(enum.IntEnum):
 
 def make_c_params(width, height, a, b, yq, cbq, crq, sf, ops, rounding=Rounding.FLOOR_HW,
                   out_format=PixelFormat.ARGB8888, strict_divisible=False,
-                  sampling=Sampling.HOLD_DECIMATE) -> N.CsicParams:
+                  sampling=Sampling.HOLD_DECIMATE, in_format=PixelFormat.ARGB8888) -> N.CsicParams:
     p = N.CsicParams()
     p.width, p.height = int(width), int(height)
     p.chroma_a, p.chroma_b = int(a), int(b)
@@ -59,7 +59,7 @@ def make_c_params(width, height, a, b, yq, cbq, crq, sf, ops, rounding=Rounding.
         p.op[k] = int(ops[k])
     p.rounding = int(rounding)
     p.sampling = int(sampling)
-    p.in_format = N.FMT_ARGB8888
+    p.in_format = int(in_format)
     p.out_format = int(out_format)
     p.strict_divisible = 1 if strict_divisible else 0
     return p

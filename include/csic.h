@@ -21,7 +21,10 @@
  *                       ignored; output alpha is 255 (ImageCompressorTopApp.scala:139).
  *   CSIC_FMT_YCBCR888X: byte0=Y byte1=Cb byte2=Cr byte3=0 -- the PixelYCbCrBundle that
  *                       ImageCompressorTop.io.out carries (ImageCompressorTop.scala:35,
- *                       PixelBundle.scala:11-15), i.e. the pipeline WITHOUT the host-side inverse.
+ *                       PixelBundle.scala:11-15), i.e. the pipeline WITHOUT the host-side inverse.  As
+ *                       in_format it feeds a YCbCr stream straight into op1 (forward transform skipped):
+ *                       how the reference's specs drive ONE stage (ChromaSubsamplerImageSpec.scala:150-170,
+ *                       ColorQuantizerSpec.scala:72-100, SpatialDownsamplerSpec.scala:20-45).
  * Frames are row-major, tightly packed (row pitch = width * 4 bytes).
  */
 #ifndef CSIC_H
@@ -84,7 +87,7 @@ typedef enum csic_status {
 #define CSIC_SAMPLING_AVG           1
 
 #define CSIC_FMT_ARGB8888  0
-#define CSIC_FMT_YCBCR888X 1  /* out_format only */
+#define CSIC_FMT_YCBCR888X 1
 
 /* ---- parameters ---------------------------------------------------------------------------------
  * Field-for-field the constructor list of

@@ -63,6 +63,15 @@ void orc_quantize(int y, int cb, int cr, int yb, int cbb, int crb, int *yq, int 
     *crq = (cr >> scr) << scr;
 }
 
+/* input pixel -> (Y, Cb, Cr): the forward transform, or plain unpacking when the caller feeds
+ * a YCbCr stream (how ChromaSubsamplerImageSpec / ColorQuantizerSpec / SpatialDownsamplerSpec
+ * drive one stage at a time) */
+static inline void decode_px(const orc_params *p, uint32_t px, int *y, int *cb, int *cr)
+{
+    if (p->in_format == ORC_FMT_YCC) { *y = px & 0xFF; *cb = (px >> 8) & 0xFF; *cr = (px >> 16) & 0xFF; }
+    else orc_rgb2ycbcr((px >> 16) & 0xFF, (px >> 8) & 0xFF, px & 0xFF, p->rounding, y, cb, cr);
+}
+
 /* ------------------------------------------------------------------------- */
 /* validation                                                                  */
 /* ------------------------------------------------------------------------- */
@@ -87,6 +96,7 @@ int orc_validate(const orc_params *p)
     }
     if (p->rounding != ORC_ROUND_FLOOR_HW && p->rounding != ORC_ROUND_TRUNC_SW) return -8;
     if (p->out_format != ORC_FMT_ARGB && p->out_format != ORC_FMT_YCC) return -9;
+    if (p->in_format != ORC_FMT_ARGB && p->in_format != ORC_FMT_YCC) return -9;
     return 0;
 }
 
@@ -181,10 +191,8 @@ long orc_process_stream(const orc_params *p, const uint32_t *in, uint32_t *out)
     long n_out = 0;
     const long n_in = (long)W * H;
     for (long i = 0; i < n_in; ++i) {
-        uint32_t px = in[i];
-        int b = px & 0xFF, g = (px >> 8) & 0xFF, r = (px >> 16) & 0xFF;   /* alpha ignored: ImageProcessorModel.scala:48 */
-        ycc_t v;
-        orc_rgb2ycbcr(r, g, b, p->rounding, &v.y, &v.cb, &v.cr);           /* toYC, ImageCompressorTop.scala:80-81 */
+        ycc_t v;                                                           /* alpha ignored: ImageProcessorModel.scala:48 */
+        decode_px(p, in[i], &v.y, &v.cb, &v.cr);                           /* toYC, ImageCompressorTop.scala:80-81 */
         int alive = 1;
         for (int k = 0; k < 3 && alive; ++k) {                             /* op1 -> op2 -> op3, :83-114 */
             switch (p->op[k]) {
@@ -247,8 +255,8 @@ long orc_process_closed_rows(const orc_params *p, const uint32_t *in, uint32_t *
             }
             uint32_t py = in[y_idx], pc = in[c_idx];
             ycc_t a, c2;
-            orc_rgb2ycbcr((py >> 16) & 0xFF, (py >> 8) & 0xFF, py & 0xFF, p->rounding, &a.y, &a.cb, &a.cr);
-            orc_rgb2ycbcr((pc >> 16) & 0xFF, (pc >> 8) & 0xFF, pc & 0xFF, p->rounding, &c2.y, &c2.cb, &c2.cr);
+            decode_px(p, py, &a.y, &a.cb, &a.cr);
+            decode_px(p, pc, &c2.y, &c2.cb, &c2.cr);
             a.cb = c2.cb; a.cr = c2.cr;
             orc_quantize(a.y, a.cb, a.cr, p->y_bits, p->cb_bits, p->cr_bits, &a.y, &a.cb, &a.cr);
             out[ro * wo + co] = pack_out(p, a);
@@ -299,9 +307,8 @@ long orc_process_avg(const orc_params *p, const uint32_t *in, uint32_t *out)
                     if (r > H - 1) r = H - 1;
                     if (c > W - 1) c = W - 1;
                     /* chroma-stage output at (r, c) */
-                    uint32_t px = in[r * W + c];
                     int y, cb, cr;
-                    orc_rgb2ycbcr((px >> 16) & 0xFF, (px >> 8) & 0xFF, px & 0xFF, p->rounding, &y, &cb, &cr);
+                    decode_px(p, in[r * W + c], &y, &cb, &cr);
                     long r0 = r - r % v, c0 = c - c % h;
                     int acb = 0, acr = 0;
                     for (int ii = 0; ii < v; ++ii) {
@@ -309,9 +316,8 @@ long orc_process_avg(const orc_params *p, const uint32_t *in, uint32_t *out)
                             long rr = r0 + ii, cc = c0 + jj;
                             if (rr > H - 1) rr = H - 1;
                             if (cc > W - 1) cc = W - 1;
-                            uint32_t q = in[rr * W + cc];
                             int y2, cb2, cr2;
-                            orc_rgb2ycbcr((q >> 16) & 0xFF, (q >> 8) & 0xFF, q & 0xFF, p->rounding, &y2, &cb2, &cr2);
+                            decode_px(p, in[rr * W + cc], &y2, &cb2, &cr2);
                             acb += cb2; acr += cr2;
                         }
                     }

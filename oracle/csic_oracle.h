@@ -48,6 +48,9 @@ typedef struct orc_params {
     int32_t op[3];                  /* permutation of {1,2,3}                    */
     int32_t rounding;               /* ORC_ROUND_*                               */
     int32_t out_format;             /* ORC_FMT_*                                 */
+    int32_t in_format;              /* ORC_FMT_ARGB, or ORC_FMT_YCC: the input already is the
+                                       Y|Cb<<8|Cr<<16 stream a single stage is driven with in the
+                                       reference's specs (forward transform skipped)            */
 } orc_params;
 
 /* ---- per-pixel functions -------------------------------------------------- */

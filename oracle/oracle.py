@@ -31,6 +31,7 @@ class _Params(C.Structure):
         ("op", C.c_int32 * 3),
         ("rounding", C.c_int32),
         ("out_format", C.c_int32),
+        ("in_format", C.c_int32),
     ]
 
 
@@ -47,6 +48,7 @@ class OracleParams:
     op: Sequence[int] = field(default_factory=lambda: (OP_CHROMA, OP_SPATIAL, OP_QUANT))
     rounding: int = ROUND_FLOOR_HW
     out_format: int = FMT_ARGB
+    in_format: int = FMT_ARGB
 
     def c(self) -> _Params:
         p = _Params()
@@ -56,7 +58,7 @@ class OracleParams:
         p.factor = self.factor
         for k in range(3):
             p.op[k] = int(self.op[k])
-        p.rounding, p.out_format = self.rounding, self.out_format
+        p.rounding, p.out_format, p.in_format = self.rounding, self.out_format, self.in_format
         return p
 
 

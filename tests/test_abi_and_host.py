@@ -232,3 +232,24 @@ def test_cli_missing_input_is_not_an_exception(tmp_path, capsys):
     assert "[ERROR] Input image not found" in outp                 # ImageCompressorTopApp.scala:197-199
     assert "Selected Spatial Downsampling Factor: 8" in outp       # default sf = 8, :170
     assert "SpatialSampling -> ColorQuantization -> ChromaSubsampling" in outp   # default order, :171-173
+
+
+def test_stage_generators_requires():
+    """Construction-time require()s of the per-stage generators (no device needed)."""
+    S = csic.stages
+    S.ChromaSubsampler(16, 16, 8, 2, 0)
+    for bad in [(0, 16, 8, 4, 4), (16, 0, 8, 4, 4), (16, 16, 10, 4, 4), (16, 16, 8, 3, 3), (16, 16, 8, 2, 1)]:
+        with pytest.raises(csic.IllegalArgumentException):        # ChromaSubsampler.scala:13-18
+            S.ChromaSubsampler(*bad)
+    S.SpatialDownsampler(4, 4, 8)
+    for bad in [(4, 4, 3), (0, 4, 2), (4, -1, 2)]:
+        with pytest.raises(csic.IllegalArgumentException):        # SpatialDownsampler.scala:7-8
+            S.SpatialDownsampler(*bad)
+    q = S.ColorQuantizer(3, 3, 2)
+    assert q._bits8 == (3, 3, 2)
+    assert S.ColorQuantizer(2, 3, 1, originalBitWidth=4)._bits8 == (6, 7, 5)
+    for bad in [(0, 8, 8, 8), (9, 8, 8, 8), (5, 4, 4, 4), (4, 4, 4, 0), (4, 4, 4, 9)]:
+        with pytest.raises(csic.IllegalArgumentException):        # ColorQuantizer.scala:12-15
+            S.ColorQuantizer(*bad)
+    ycc = csic.pack_ycc([[1, 2]], [[3, 4]], [[5, 6]])
+    assert [c.tolist() for c in csic.unpack_ycc(ycc)] == [[[1, 2]], [[3, 4]], [[5, 6]]]
