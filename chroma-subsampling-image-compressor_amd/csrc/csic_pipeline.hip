@@ -86,7 +86,7 @@ int csic_pipeline_create(csic_plan *plan, int32_t depth, csic_pipeline **out)
     plan_sizes(plan, &pp->in_px, &pp->out_px);
     int st = set_dev(pp);
     if (st != CSIC_OK) { delete pp; return st; }
-    pp->slots.resize(depth);
+    try { pp->slots.resize(depth); } catch (const std::bad_alloc &) { delete pp; return set_error(CSIC_ENOMEM, "out of host memory"); }
     hipError_t e = hipSuccess;
     for (auto &s : pp->slots) {
         if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_in), pp->in_px * 4, hipHostMallocMapped);

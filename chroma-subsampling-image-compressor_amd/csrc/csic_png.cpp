@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "csic_internal.h"
@@ -99,9 +100,7 @@ inline int paeth(int a, int b, int c)
 
 } // namespace
 
-extern "C" {
-
-int csic_png_info(const char *path, int32_t *width, int32_t *height)
+static int png_info_impl(const char *path, int32_t *width, int32_t *height)
 {
     if (!path || !width || !height) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
     std::vector<unsigned char> f;
@@ -115,7 +114,7 @@ int csic_png_info(const char *path, int32_t *width, int32_t *height)
     return CSIC_OK;
 }
 
-int csic_png_read_argb(const char *path, uint32_t *dst, size_t dst_px)
+static int png_read_impl(const char *path, uint32_t *dst, size_t dst_px)
 {
     if (!path || !dst) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
     std::vector<unsigned char> f, plte, idat;
@@ -180,7 +179,7 @@ int csic_png_read_argb(const char *path, uint32_t *dst, size_t dst_px)
     return CSIC_OK;
 }
 
-int csic_png_write_argb(const char *path, const uint32_t *src, int32_t width, int32_t height, int32_t level)
+static int png_write_impl(const char *path, const uint32_t *src, int32_t width, int32_t height, int32_t level)
 {
     if (!path || !src) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
     if (width <= 0 || height <= 0) return set_error(CSIC_EINVAL_DIMS, "width and height must be positive. Got %dx%d", width, height);
@@ -232,6 +231,23 @@ int csic_png_write_argb(const char *path, const uint32_t *src, int32_t width, in
     if (!ok) return set_error(CSIC_EIO, "write to %s failed", path);
     clear_error();
     return CSIC_OK;
+}
+
+// No C++ exception may cross the C ABI: allocation failures become CSIC_ENOMEM.
+#define CSIC_NOEXCEPT_CALL(expr)                                                        \
+    try { return (expr); }                                                              \
+    catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); } \
+    catch (...) { return set_error(CSIC_EIO, "unexpected failure in the PNG codec"); }
+
+extern "C" {
+
+int csic_png_info(const char *path, int32_t *width, int32_t *height) { CSIC_NOEXCEPT_CALL(png_info_impl(path, width, height)) }
+
+int csic_png_read_argb(const char *path, uint32_t *dst, size_t dst_px) { CSIC_NOEXCEPT_CALL(png_read_impl(path, dst, dst_px)) }
+
+int csic_png_write_argb(const char *path, const uint32_t *src, int32_t width, int32_t height, int32_t level)
+{
+    CSIC_NOEXCEPT_CALL(png_write_impl(path, src, width, height, level))
 }
 
 } // extern "C"

@@ -1,0 +1,107 @@
+// host_sanitize.cpp -- ASan/UBSan driver for the host-only half of the library (no HIP): parameter
+// validation, geometry, stripes, and the PNG codec under a mutation fuzzer that re-signs chunk CRCs so
+// that corrupt payloads reach the inflate / unfilter / unpack code.  Built and run by
+// tests/test_sanitizers.py with  g++ -fsanitize=address,undefined  (CPU only; GPU ASan is unavailable).
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "csic.h"
+
+static uint32_t rng_state = 12345;
+static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 17; rng_state ^= rng_state << 5; return rng_state; }
+
+static std::vector<unsigned char> slurp(const char *p)
+{
+    std::vector<unsigned char> b;
+    FILE *f = std::fopen(p, "rb");
+    if (!f) return b;
+    std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+    b.resize(n); if (std::fread(b.data(), 1, n, f) != (size_t)n) b.clear();
+    std::fclose(f);
+    return b;
+}
+
+static void resign(std::vector<unsigned char> &png)      // recompute every chunk CRC
+{
+    size_t pos = 8;
+    while (pos + 12 <= png.size()) {
+        uint32_t len = (png[pos] << 24) | (png[pos + 1] << 16) | (png[pos + 2] << 8) | png[pos + 3];
+        if (pos + 12 + (size_t)len > png.size()) break;
+        uint32_t crc = crc32(crc32(0, Z_NULL, 0), &png[pos + 4], 4 + len);
+        png[pos + 8 + len] = crc >> 24; png[pos + 9 + len] = crc >> 16; png[pos + 10 + len] = crc >> 8; png[pos + 11 + len] = crc;
+        pos += 12 + len;
+    }
+}
+
+int main(int argc, char **argv)
+{
+    // ---- validation / geometry / stripes over a grid of good and bad parameters
+    long checked = 0;
+    for (int W : {-1, 0, 1, 5, 16, 8192, 65536}) for (int H : {0, 1, 3, 4096, 40000})
+    for (int f : {0, 1, 2, 3, 4, 8, 16}) for (int a : {0, 1, 2, 3, 4}) for (int b : {0, 1, 2, 4})
+    for (int o = 0; o < 4; ++o) {
+        csic_params p; csic_params_default(&p, W, H);
+        p.factor = f; p.chroma_a = a; p.chroma_b = b;
+        const int ops[4][3] = {{3, 1, 2}, {1, 2, 3}, {1, 1, 2}, {0, 7, -3}};
+        for (int k = 0; k < 3; ++k) p.op[k] = ops[o][k];
+        p.sampling = o & 1;
+        int32_t wo, ho, r0, nr, o0, on; int64_t bytes;
+        int st = csic_validate(&p);
+        int st2 = csic_out_dims(&p, &wo, &ho), st3 = csic_algorithmic_bytes(&p, &bytes);
+        if ((st == 0) != (st2 == 0) || (st == 0) != (st3 == 0)) { std::printf("inconsistent validation\n"); return 1; }
+        for (int n : {1, 2, 7, 8}) for (int r = 0; r < n; ++r) (void)csic_stripe_rows(&p, n, r, &r0, &nr, &o0, &on);
+        (void)csic_strerror(st); (void)csic_last_error();
+        ++checked;
+    }
+    // ---- PNG codec: round trip, then mutation fuzzing of every fixture given on the command line
+    std::vector<uint32_t> img(37 * 23);
+    for (auto &v : img) v = rnd();
+    const std::string tmp = std::string(argv[1]) + "/rt.png";
+    if (csic_png_write_argb(tmp.c_str(), img.data(), 37, 23, 6) != 0) { std::printf("write failed\n"); return 1; }
+    std::vector<uint32_t> back(37 * 23);
+    if (csic_png_read_argb(tmp.c_str(), back.data(), back.size()) != 0) { std::printf("read failed\n"); return 1; }
+    for (size_t i = 0; i < img.size(); ++i) if ((img[i] | 0xFF000000u) != back[i]) { std::printf("roundtrip mismatch\n"); return 1; }
+    long fuzzed = 0, accepted = 0;
+    const std::string mut = std::string(argv[1]) + "/mut.png";
+    for (int a = 2; a < argc; ++a) {
+        const std::vector<unsigned char> orig = slurp(argv[a]);
+        if (orig.empty()) { std::printf("cannot read %s\n", argv[a]); return 1; }
+        int32_t w = 0, h = 0;
+        if (csic_png_info(argv[a], &w, &h) != 0) { std::printf("info failed on %s\n", argv[a]); return 1; }
+        std::vector<uint32_t> dst((size_t)w * h);
+        const int iters = orig.size() > 100000 ? 60 : 400;
+        for (int it = 0; it < iters; ++it) {
+            std::vector<unsigned char> m = orig;
+            const int nmut = 1 + rnd() % 4;
+            for (int k = 0; k < nmut; ++k) {
+                const size_t pos = 8 + rnd() % (m.size() - 8);
+                switch (rnd() % 4) {
+                case 0: m[pos] ^= 1u << (rnd() % 8); break;
+                case 1: m[pos] = (unsigned char)rnd(); break;
+                case 2: if (m.size() > 64) m.resize(m.size() - 1 - rnd() % 32); break;   // truncate
+                default: m[16 + rnd() % 13] = (unsigned char)(rnd() % 20); break;       // IHDR fields
+                }
+            }
+            if (rnd() % 4) resign(m);
+            FILE *f = std::fopen(mut.c_str(), "wb");
+            std::fwrite(m.data(), 1, m.size(), f); std::fclose(f);
+            int32_t w2, h2;
+            if (csic_png_info(mut.c_str(), &w2, &h2) == 0) {
+                // the destination is sized from the (possibly mutated) header, like a real caller would do
+                if ((int64_t)w2 * h2 <= (1 << 24)) {
+                    std::vector<uint32_t> d2((size_t)w2 * h2);
+                    if (csic_png_read_argb(mut.c_str(), d2.data(), d2.size()) == 0) ++accepted;
+                }
+                (void)csic_png_read_argb(mut.c_str(), dst.data(), dst.size());   // and with a mismatching size
+            }
+            ++fuzzed;
+        }
+    }
+    std::printf("sanitize ok: %ld parameter sets, %ld fuzzed PNGs (%ld still decodable)\n", checked, fuzzed, accepted);
+    return 0;
+}
