@@ -1,0 +1,29 @@
+# Convenience targets (the driver uses __graft_entry__.build() / pytest / bench.py directly).
+PKG := chroma-subsampling-image-compressor_amd
+
+build:
+	$(MAKE) -C $(PKG)/csrc
+	$(MAKE) -C oracle
+
+test: build
+	python -m pytest tests -x -q -m "not gpu"
+
+test-gpu: build
+	python -m pytest tests -x -q -m gpu
+
+bench: build
+	python bench.py
+
+asm:
+	$(MAKE) -C $(PKG)/csrc asm
+
+ubench: build
+	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -I$(PKG)/csrc tools/ubench.hip \
+		$(PKG)/csrc/csic_host.cpp $(PKG)/csrc/csic_png.cpp -lz -o tools/ubench
+
+clean:
+	$(MAKE) -C $(PKG)/csrc clean
+	$(MAKE) -C oracle clean
+	rm -f tools/ubench tests/cpp/host_test
+
+.PHONY: build test test-gpu bench asm ubench clean

@@ -1,0 +1,46 @@
+"""bench.py's contract pieces that can be checked without a GPU: the CPU-baseline leg (the only place
+outside tests/ and smoke() that may touch the oracle), the config table and the argument surface."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _load_bench():
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_cpu_baseline_object_shape():
+    bench = _load_bench()
+    cb = bench.cpu_baseline(256, 128, 2, 0, (8, 8, 8), 2, budget_s=0.2)
+    assert cb["unit"] == "Mpixels/s" and cb["cores"] == 1 and cb["kind"] == "port" and cb["value"] > 0
+    assert "orc_process_stream" in cb["sample"]
+    assert cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > 0
+    json.dumps(cb)
+
+
+def test_config_table_matches_baseline_json():
+    bench = _load_bench()
+    assert bench.CONFIGS["cfg4"] == (8192, 8192, 2, 0, (8, 8, 8), 2, 1)       # 8192x8192, 4:2:0, sf=2
+    assert bench.CONFIGS["cfg5"] == (3840, 2160, 2, 0, (3, 3, 2), 4, 64)       # 64 x 4K, 4:2:0, sf=4, Q_8BIT
+    assert bench.CONFIGS["cfg3"] == (512, 512, 2, 0, (3, 3, 2), 2, 1)
+    assert bench.CONFIGS["cfg2"] == (128, 128, 2, 2, (3, 3, 2), 1, 1)
+    assert bench.HBM_PEAK_GBS == 8000.0
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "Mpixels/s" in base["metric"]
+
+
+def test_bench_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stdout + r.stderr)
