@@ -70,6 +70,7 @@ PROTOTYPES = {
     "csic_out_dims": (C.c_int, [C.POINTER(CsicParams), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "csic_algorithmic_bytes": (C.c_int, [C.POINTER(CsicParams), C.POINTER(C.c_int64)]),
     "csic_stripe_rows": (C.c_int, [C.POINTER(CsicParams), C.c_int32, C.c_int32] + [C.POINTER(C.c_int32)] * 4),
+    "csic_stripe_halo": (C.c_int, [C.POINTER(CsicParams), C.c_int32, C.c_int32, C.POINTER(C.c_int32)] + [C.POINTER(C.c_int32)] * 6),
     "csic_strerror": (C.c_char_p, [C.c_int]),
     "csic_last_error": (C.c_char_p, []),
     "csic_device_count": (C.c_int, []),

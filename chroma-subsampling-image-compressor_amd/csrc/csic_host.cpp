@@ -158,6 +158,20 @@ int csic_algorithmic_bytes(const csic_params *p, int64_t *bytes)
     return CSIC_OK;
 }
 
+// alignment unit of independent row blocks (see csic_stripe_rows)
+static int stripe_unit(const Geometry &g, const csic_params *p, int64_t *L)
+{
+    if (!g.s_first || p->sampling == CSIC_SAMPLING_AVG) {
+        *L = (g.v > g.f) ? g.v : g.f;
+        return CSIC_OK;
+    }
+    if (g.W % g.f != 0)
+        return set_error(CSIC_EINVAL_STRIPE,
+                         "spatial-before-chroma with width %% factor != 0 cannot be row-striped independently");
+    *L = (int64_t)g.v * g.f * g.f;
+    return CSIC_OK;
+}
+
 int csic_stripe_rows(const csic_params *p, int32_t nranks, int32_t rank,
                      int32_t *row0, int32_t *nrows, int32_t *out_row0, int32_t *out_nrows)
 {
@@ -167,20 +181,14 @@ int csic_stripe_rows(const csic_params *p, int32_t nranks, int32_t rank,
     if (st != CSIC_OK) return st;
     if (nranks <= 0 || rank < 0 || rank >= nranks)
         return set_error(CSIC_EINVAL_STRIPE, "bad rank %d of %d", rank, nranks);
+    // Chroma before spatial (and the AVG extension): chroma indices are image coordinates, so a stripe that
+    // starts on a row that is both a vertical chroma (block) row and a decimation (pooling) row depends on
+    // nothing above it: L = lcm(v, f) = max(v, f).  Spatial before chroma: chroma runs on the decimated
+    // stream with its column counter modulo the FULL width W (ImageCompressorTop.scala:52-58): one chroma
+    // row = W decimated pixels = f decimated rows = f*f input rows, and only when f divides W.
     int64_t L;
-    if (!g.s_first) {
-        // chroma indices are image coordinates: a stripe that starts on a row that is both a
-        // vertical chroma sample row and a decimation row depends on nothing above it.
-        L = (g.v > g.f) ? g.v : g.f;               // lcm of two powers of two
-    } else {
-        // chroma runs on the decimated stream with column counter modulo the FULL width W
-        // (ImageCompressorTop.scala:52-58): one chroma row = W decimated pixels = f decimated rows
-        // = f*f input rows, and only when f divides W.
-        if (g.W % g.f != 0)
-            return set_error(CSIC_EINVAL_STRIPE,
-                             "spatial-before-chroma with width %% factor != 0 cannot be row-striped independently");
-        L = (int64_t)g.v * g.f * g.f;
-    }
+    st = stripe_unit(g, p, &L);
+    if (st != CSIC_OK) return st;
     const int64_t blocks = (g.H + L - 1) / L;
     const int64_t b0 = blocks * rank / nranks, b1 = blocks * (rank + 1) / nranks;
     int64_t r0 = b0 * L, r1 = b1 * L;
@@ -189,6 +197,40 @@ int csic_stripe_rows(const csic_params *p, int32_t nranks, int32_t rank,
     *row0 = (int32_t)r0; *nrows = (int32_t)(r1 - r0);
     *out_row0 = (int32_t)(r0 / g.f);                         // r0 is a multiple of f
     *out_nrows = (int32_t)(((r1 - r0) + g.f - 1) / g.f);
+    clear_error();
+    return CSIC_OK;
+}
+
+int csic_stripe_halo(const csic_params *p, int32_t nranks, int32_t rank, const int32_t *row_splits,
+                     int32_t *proc_row0, int32_t *proc_nrows, int32_t *halo_above, int32_t *tail_below,
+                     int32_t *out_row0, int32_t *out_nrows)
+{
+    if (!row_splits || !proc_row0 || !proc_nrows || !halo_above || !tail_below || !out_row0 || !out_nrows)
+        return set_error(CSIC_EINVAL_NULL, "argument is NULL");
+    Geometry g;
+    int st = derive_geometry(p, &g);
+    if (st != CSIC_OK) return st;
+    if (nranks <= 0 || rank < 0 || rank >= nranks) return set_error(CSIC_EINVAL_STRIPE, "bad rank %d of %d", rank, nranks);
+    if (row_splits[0] != 0 || row_splits[nranks] != g.H)
+        return set_error(CSIC_EINVAL_STRIPE, "row_splits must start at 0 and end at height %d", g.H);
+    for (int r = 0; r < nranks; ++r)
+        if (row_splits[r + 1] < row_splits[r]) return set_error(CSIC_EINVAL_STRIPE, "row_splits must be non-decreasing");
+    int64_t L;
+    st = stripe_unit(g, p, &L);
+    if (st != CSIC_OK) return st;
+    // aligned-down boundary in front of every stripe; the last one is the true end of the frame
+    auto lo = [&](int r) -> int64_t { return r >= nranks ? g.H : (row_splits[r] / L) * L; };
+    for (int r = 1; r < nranks; ++r)          // the halo of rank r must live entirely on rank r-1
+        if (lo(r) < row_splits[r - 1])
+            return set_error(CSIC_EINVAL_STRIPE, "stripe %d (%d rows) is shorter than the %lld-row halo rank %d needs",
+                             r - 1, row_splits[r] - row_splits[r - 1], (long long)(row_splits[r] - lo(r)), r);
+    const int64_t a = lo(rank), b = lo(rank + 1);
+    *proc_row0 = (int32_t)a;
+    *proc_nrows = (int32_t)(b - a);
+    *halo_above = (int32_t)(row_splits[rank] - a);
+    *tail_below = (int32_t)(row_splits[rank + 1] - b);         // 0 on the last rank (b = H)
+    *out_row0 = (int32_t)(a / g.f);
+    *out_nrows = (int32_t)((b - a + g.f - 1) / g.f);
     clear_error();
     return CSIC_OK;
 }

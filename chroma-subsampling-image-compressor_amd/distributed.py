@@ -7,6 +7,12 @@ runs before the decimator, v*f*f when it runs behind it), which makes each strip
 image: the 4:2:0 odd-row hold (ChromaSubsampler.scala:52-65) only ever looks one row up, and that row
 is in the same stripe.  Hence NO data-path collective and no halo: the only communication is the
 optional gather of the finished output stripes.
+
+When the frame arrives ALREADY partitioned at rows the caller chose (`row_splits`), boundaries may fall
+inside an L-row block.  Then every rank still processes whole aligned blocks: csic_stripe_halo tells it to
+send its trailing rows (those past its last aligned boundary, fewer than L) to the next rank and to
+receive the matching rows from the previous one -- a single neighbour exchange (NCCL/RCCL send/recv
+over xGMI between adjacent GPUs; a few rows, never link-bound), after which the kernel runs unchanged.
 """
 from __future__ import annotations
 
@@ -27,6 +33,21 @@ class Stripe:
     nrows: int       # number of input rows
     out_row0: int    # first output row produced
     out_nrows: int   # number of output rows
+    halo_above: int = 0   # rows received from rank-1 (unaligned row_splits only)
+    tail_below: int = 0   # rows sent to rank+1
+    proc_row0: int = -1   # first row of the aligned range this rank processes (== row0 - halo_above)
+    proc_nrows: int = -1  # rows of that range (== halo_above + nrows - tail_below)
+
+
+def halo_stripe_for_rank(c_params: N.CsicParams, row_splits, rank: int) -> Stripe:
+    """Stripe description for a frame that is pre-partitioned at `row_splits` (csic_stripe_halo)."""
+    nranks = len(row_splits) - 1
+    arr = (C.c_int32 * (nranks + 1))(*[int(x) for x in row_splits])
+    v = [C.c_int32() for _ in range(6)]
+    N.check(N.lib().csic_stripe_halo(C.byref(c_params), nranks, rank, arr, *[C.byref(x) for x in v]))
+    pr0, pn, halo, tail, o0, on = (x.value for x in v)
+    return Stripe(rank, nranks, int(row_splits[rank]), int(row_splits[rank + 1] - row_splits[rank]), o0, on,
+                  halo, tail, pr0, pn)
 
 
 def stripe_for_rank(c_params: N.CsicParams, nranks: int, rank: int) -> Stripe:
@@ -49,7 +70,7 @@ class StripedImageCompressorTop:
                  yTargetQuantBitsConfig, cbTargetQuantBitsConfig, crTargetQuantBitsConfig, downFactorConfig,
                  op1Type, op2Type, op3Type, *, rounding=Rounding.FLOOR_HW, out_format=PixelFormat.ARGB8888,
                  group=None, device: Optional[int] = None,
-                 plan_factory: Callable[[N.CsicParams, int], object] = Plan):
+                 plan_factory: Callable[[N.CsicParams, int], object] = Plan, row_splits=None):
         import torch.distributed as dist
         self._dist = dist
         self.group = group
@@ -60,20 +81,57 @@ class StripedImageCompressorTop:
                        cbTargetQuantBitsConfig, crTargetQuantBitsConfig, downFactorConfig, ops)
         self.global_params = make_c_params(width, height, *self._gargs, rounding=rounding, out_format=out_format)
         N.check(N.lib().csic_validate(C.byref(self.global_params)))
-        self.stripe = stripe_for_rank(self.global_params, self.nranks, self.rank)
-        self.stripes = [stripe_for_rank(self.global_params, self.nranks, r) for r in range(self.nranks)]
+        if row_splits is None:
+            self.stripes = [stripe_for_rank(self.global_params, self.nranks, r) for r in range(self.nranks)]
+        else:
+            if len(row_splits) != self.nranks + 1:
+                raise N.IllegalArgumentException(N.EINVAL_STRIPE, "requirement failed: row_splits needs nranks + 1 entries")
+            self.stripes = [halo_stripe_for_rank(self.global_params, row_splits, r) for r in range(self.nranks)]
+        self.stripe = self.stripes[self.rank]
         wo, ho = C.c_int32(), C.c_int32()
         N.check(N.lib().csic_out_dims(C.byref(self.global_params), C.byref(wo), C.byref(ho)))
         self.out_width, self.out_height = wo.value, ho.value
         self.device = self.rank if device is None else device
         self._plan = None
-        if self.stripe.nrows > 0:
-            sp = make_c_params(width, self.stripe.nrows, *self._gargs, rounding=rounding, out_format=out_format)
+        self._proc_rows = self.stripe.nrows if self.stripe.proc_nrows < 0 else self.stripe.proc_nrows
+        if self._proc_rows > 0:
+            sp = make_c_params(width, self._proc_rows, *self._gargs, rounding=rounding, out_format=out_format)
             self._plan = plan_factory(sp, self.device)
+
+    def _exchange_halo(self, local_rows):
+        """One neighbour exchange: my trailing `tail_below` rows go to rank+1, `halo_above` rows arrive from
+        rank-1 (isend/irecv pairs: NCCL send/recv over xGMI on GPUs, gloo in the CPU tests).  Returns the
+        aligned range [proc_row0, proc_row0 + proc_nrows) this rank processes."""
+        import numpy as np
+        import torch
+        dist, st = self._dist, self.stripe
+        W = self.global_params.width
+        is_np = not hasattr(local_rows, "is_cuda")
+        t = torch.from_numpy(np.ascontiguousarray(local_rows).view(np.int32).reshape(-1, W)) if is_np \
+            else local_rows.reshape(-1, W)
+        ops, halo = [], None
+        if st.tail_below > 0:
+            tail = t[st.nrows - st.tail_below:].contiguous()
+            ops.append(dist.P2POp(dist.isend, tail, self._global_rank(self.rank + 1), self.group))
+        if st.halo_above > 0:
+            halo = torch.empty((st.halo_above, W), dtype=t.dtype, device=t.device)
+            ops.append(dist.P2POp(dist.irecv, halo, self._global_rank(self.rank - 1), self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        body = t[: st.nrows - st.tail_below]
+        ext = body if halo is None else torch.cat([halo, body], 0)
+        return ext.numpy().view(np.uint32) if is_np else ext.contiguous()
+
+    def _global_rank(self, group_rank: int) -> int:
+        return group_rank if self.group is None else self._dist.get_global_rank(self.group, group_rank)
 
     def process_local(self, local_rows):
         """local_rows: this rank's input rows [row0, row0+nrows) (numpy uint32 or CUDA tensor, nrows x W).
-        Returns its output rows (out_nrows x out_width)."""
+        Returns its output rows (out_nrows x out_width).  With unaligned `row_splits` this first performs the
+        single neighbour halo exchange (collective: every rank must call it)."""
+        if self.stripe.proc_nrows >= 0 and self.nranks > 1:
+            local_rows = self._exchange_halo(local_rows)
         if self._plan is None:
             return None
         return self._plan.process(local_rows)

@@ -141,6 +141,18 @@ int  csic_algorithmic_bytes(const csic_params *p, int64_t *bytes);
 int  csic_stripe_rows(const csic_params *p, int32_t nranks, int32_t rank,
                       int32_t *row0, int32_t *nrows, int32_t *out_row0, int32_t *out_nrows);
 
+/* Halo plan for stripes that are ALREADY partitioned at arbitrary rows (row_splits[0..nranks], with
+ * row_splits[0] = 0 and row_splits[nranks] = height): rank r holds input rows [row_splits[r], row_splits[r+1]).
+ * Every rank processes whole aligned L-row blocks [*proc_row0, *proc_row0 + *proc_nrows): it RECEIVES the
+ * *halo_above = row_splits[r] - *proc_row0 rows in front of its stripe from rank r-1 and SENDS its trailing
+ * *tail_below rows (those past its last aligned boundary) to rank r+1 -- one neighbour exchange of fewer than
+ * L rows (the north star's "single RCCL halo exchange"; L as in csic_stripe_rows).  The processed range is an
+ * independent image; its output rows are [*out_row0, *out_row0 + *out_nrows).  Fails with
+ * CSIC_EINVAL_STRIPE if a stripe is shorter than the halo its successor needs. */
+int  csic_stripe_halo(const csic_params *p, int32_t nranks, int32_t rank, const int32_t *row_splits,
+                      int32_t *proc_row0, int32_t *proc_nrows, int32_t *halo_above, int32_t *tail_below,
+                      int32_t *out_row0, int32_t *out_nrows);
+
 const char *csic_strerror(int status);
 const char *csic_last_error(void);       /* thread-local; "" when the last call succeeded */
 

@@ -54,7 +54,15 @@ int main(int argc, char **argv)
         int st = csic_validate(&p);
         int st2 = csic_out_dims(&p, &wo, &ho), st3 = csic_algorithmic_bytes(&p, &bytes);
         if ((st == 0) != (st2 == 0) || (st == 0) != (st3 == 0)) { std::printf("inconsistent validation\n"); return 1; }
-        for (int n : {1, 2, 7, 8}) for (int r = 0; r < n; ++r) (void)csic_stripe_rows(&p, n, r, &r0, &nr, &o0, &on);
+        for (int n : {1, 2, 7, 8}) for (int r = 0; r < n; ++r) {
+            (void)csic_stripe_rows(&p, n, r, &r0, &nr, &o0, &on);
+            int32_t splits[9], pr0, pn, halo, tail;
+            splits[0] = 0;
+            for (int k = 1; k < n; ++k) splits[k] = (H > 0) ? (int32_t)(rnd() % (unsigned)(H + 1)) : 0;
+            splits[n] = H;
+            for (int i = 1; i < n; ++i) for (int j = i + 1; j < n; ++j) if (splits[j] < splits[i]) { int32_t t = splits[i]; splits[i] = splits[j]; splits[j] = t; }
+            (void)csic_stripe_halo(&p, n, r, splits, &pr0, &pn, &halo, &tail, &o0, &on);
+        }
         (void)csic_strerror(st); (void)csic_last_error();
         ++checked;
     }
