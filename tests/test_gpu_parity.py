@@ -502,3 +502,14 @@ def test_avg_extension_rejects_other_orders(csic):
     top = csic.ImageCompressorTop(16, 16, 2, 0, 8, 8, 8, 2, 3, 1, 2, sampling=csic.Sampling.AVG)
     assert top.process(np.zeros((16, 16), np.uint32)).shape == (8, 8)
     top.close()
+
+
+@pytest.mark.parametrize("W,H", [(1920, 1080), (3840, 540), (1280, 720), (960, 64), (2880, 90), (7680, 64), (1000, 50), (4100, 33)])
+def test_video_widths_tile_exactly(csic, oracle, W, H):
+    """Widths that are not a multiple of the 1024-pixel chunk (1080p, 4K, 720p, ...): the launch picks a block
+    width that divides the row, or falls back to the clamped partial-chunk path; both must be exact."""
+    argb = oracle.synth_frame(W * H, W + H)
+    for (a, b, f, op) in [(2, 0, 2, CSQ), (2, 0, 4, CSQ), (1, 1, 2, CSQ), (2, 0, 1, CSQ), (2, 2, 2, (1, 2, 3)), (2, 0, 8, CSQ)]:
+        want = oracle.process(_oparams(oracle, W, H, a, b, (3, 3, 2), f, op), argb, form="closed")
+        with _plan(csic, W, H, a, b, (3, 3, 2), f, op) as pl:
+            assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H, a, b, f, op)
