@@ -14,12 +14,12 @@ from .pipeline import FramePipeline
 from .stages import (ChromaSubsampler, ColorQuantizer, ReferenceModel, RGB2YCbCr, SpatialDownsampler, YCbCrUtils,
                      pack_ycc, unpack_ycc)
 from .app import ImageCompressionApp
-from .distributed import Stripe, StripedImageCompressorTop, halo_stripe_for_rank, stripe_for_rank
+from .distributed import MultiDeviceCompressor, Stripe, StripedImageCompressorTop, halo_stripe_for_rank, stripe_for_rank
 from . import app, compressor, distributed, model, params, pipeline, stages
 
 __all__ = [
     "CsicIOError", "CsicRuntimeError", "IllegalArgumentException", "ImageProcessorParams", "PixelFormat", "ProcessingStep",
     "Rounding", "Sampling", "make_c_params", "ImageCompressorTop", "ImageProcessor", "Plan", "Image", "ImageProcessorModel",
     "ImageCompressionApp", "FramePipeline", "ChromaSubsampler", "ColorQuantizer", "ReferenceModel", "RGB2YCbCr",
-    "SpatialDownsampler", "YCbCrUtils", "pack_ycc", "unpack_ycc", "Stripe", "StripedImageCompressorTop", "halo_stripe_for_rank", "stripe_for_rank",
+    "SpatialDownsampler", "YCbCrUtils", "pack_ycc", "unpack_ycc", "Stripe", "StripedImageCompressorTop", "MultiDeviceCompressor", "halo_stripe_for_rank", "stripe_for_rank",
 ]

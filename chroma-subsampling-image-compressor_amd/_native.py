@@ -93,6 +93,13 @@ PROTOTYPES = {
     "csic_pipeline_collect": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]),
     "csic_pipeline_pending": (C.c_int, [C.c_void_p]),
     "csic_pipeline_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
+    "csic_multi_create": (C.c_int, [C.POINTER(CsicParams), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]),
+    "csic_multi_destroy": (C.c_int, [C.c_void_p]),
+    "csic_multi_count": (C.c_int, [C.c_void_p]),
+    "csic_multi_stripe": (C.c_int, [C.c_void_p, C.c_int32] + [C.POINTER(C.c_int32)] * 5),
+    "csic_multi_process_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "csic_multi_synchronize": (C.c_int, [C.c_void_p]),
+    "csic_multi_process_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
 }
 
 _lib = None

@@ -831,6 +831,7 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
         KArgs b = a;
         b.in += (int64_t)f0 * a.in_frame_px;
         b.out += (int64_t)f0 * a.out_frame_px;
+        (void)hipGetLastError();                      // drop a stale error of an earlier, unrelated runtime call
         hipLaunchKernelGGL(fn, dim3(gx, gy, (unsigned)nz), block, 0, stream, b);
         HIP_TRY(hipGetLastError());
     }
@@ -956,6 +957,7 @@ int csic_synth_frame_device(void *d_dst, int64_t npix, int64_t first_index, uint
     if (npix == 0) return CSIC_OK;
     int64_t blocks = (npix + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
                        static_cast<uint32_t *>(d_dst), npix, first_index, seed * 0x9E3779B9u);
     HIP_TRY(hipGetLastError());
@@ -973,6 +975,7 @@ int csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *h
     if (e == hipSuccess && npix > 0) {
         int64_t blocks = (npix + 255) / 256;
         if (blocks > 4096) blocks = 4096;
+        (void)hipGetLastError();
         hipLaunchKernelGGL(k_checksum, dim3((unsigned)blocks), dim3(256), 0, s,
                            static_cast<const uint32_t *>(d_src), npix, d_sum);
         e = hipGetLastError();

@@ -166,3 +166,57 @@ class StripedImageCompressorTop:
     def close(self):
         if self._plan is not None and hasattr(self._plan, "close"):
             self._plan.close()
+
+
+class MultiDeviceCompressor:
+    """One frame striped over several devices from ONE process (csic_multi_* of include/csic.h); a device may
+    be listed more than once.  The per-process-per-GPU driver above is what bench.py uses."""
+
+    def __init__(self, c_params: N.CsicParams, devices):
+        self._h = C.c_void_p()
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        N.check(N.lib().csic_multi_create(C.byref(c_params), arr, len(self.devices), C.byref(self._h)))
+        wo, ho = C.c_int32(), C.c_int32()
+        N.check(N.lib().csic_out_dims(C.byref(c_params), C.byref(wo), C.byref(ho)))
+        self.width, self.height, self.out_width, self.out_height = c_params.width, c_params.height, wo.value, ho.value
+        self.stripes = []
+        for i in range(len(self.devices)):
+            v = [C.c_int32() for _ in range(5)]
+            N.check(N.lib().csic_multi_stripe(self._h, i, *[C.byref(x) for x in v]))
+            self.stripes.append(Stripe(i, len(self.devices), v[1].value, v[2].value, v[3].value, v[4].value))
+
+    def process_host(self, argb):
+        import numpy as np
+        a = np.ascontiguousarray(argb, dtype=np.uint32).reshape(-1)
+        out = np.empty(self.out_width * self.out_height, dtype=np.uint32)
+        N.check(N.lib().csic_multi_process_host(self._h, a.ctypes.data_as(C.c_void_p), a.size,
+                                                out.ctypes.data_as(C.c_void_p), out.size))
+        return out.reshape(self.out_height, self.out_width)
+
+    def process_device(self, d_ins, d_outs=None):
+        """d_ins[i]: CUDA tensor on devices[i] with stripe i's input rows.  Returns the list of output tensors
+        (asynchronous; call synchronize())."""
+        import torch
+        if d_outs is None:
+            d_outs = [torch.empty((s.out_nrows, self.out_width), dtype=t.dtype, device=t.device)
+                      for s, t in zip(self.stripes, d_ins)]
+        n = len(self.devices)
+        pin = (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) for t in d_ins])
+        pout = (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) for t in d_outs])
+        N.check(N.lib().csic_multi_process_device(self._h, pin, pout))
+        return d_outs
+
+    def synchronize(self) -> None:
+        N.check(N.lib().csic_multi_synchronize(self._h))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            N.lib().csic_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

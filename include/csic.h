@@ -248,6 +248,25 @@ int  csic_pipeline_pending(const csic_pipeline *pipeline);
 #define CSIC_PIPELINE_ZERO_COPY 1
 int  csic_pipeline_set_mode(csic_pipeline *pipeline, int32_t mode);
 
+/* ---- several devices from one process --------------------------------------------------------------
+ * The same aligned row-stripe partition as csic_stripe_rows, for hosts that own all GPUs in ONE process
+ * (a JVM, a C++ service); bench.py and the Python driver use one process per GPU instead.  Stripe i runs on
+ * devices[i] (a device may be listed more than once) on a stream of its own; stripes are independent images,
+ * so there is no halo and no peer traffic.
+ *   csic_multi_process_device : d_in[i] / d_out[i] are device pointers ON devices[i] holding stripe i's input
+ *                               rows / receiving its output rows (see csic_multi_stripe); asynchronous --
+ *                               finish with csic_multi_synchronize.
+ *   csic_multi_process_host   : whole frame in host memory: scatter, process, gather; synchronous. */
+typedef struct csic_multi csic_multi;
+int  csic_multi_create(const csic_params *p, const int32_t *devices, int32_t ndev, csic_multi **out);
+int  csic_multi_destroy(csic_multi *multi);
+int  csic_multi_count(const csic_multi *multi);
+int  csic_multi_stripe(const csic_multi *multi, int32_t idx, int32_t *device, int32_t *row0, int32_t *nrows,
+                       int32_t *out_row0, int32_t *out_nrows);
+int  csic_multi_process_device(csic_multi *multi, const void *const *d_in, void *const *d_out);
+int  csic_multi_synchronize(csic_multi *multi);
+int  csic_multi_process_host(csic_multi *multi, const uint32_t *in, size_t in_px, uint32_t *out, size_t out_px);
+
 #ifdef __cplusplus
 }
 #endif

@@ -574,3 +574,24 @@ def test_more_than_65535_frames_per_call(csic, oracle):
         got2 = pl.process_device(torch.from_numpy(host_in2.view(np.int32)).cuda(), nframes=n).cpu().numpy().view(np.uint32)
     diff = np.nonzero((got != got2).reshape(n, -1).any(1))[0]
     assert diff.tolist() == [7]
+
+
+def test_single_process_multi_device_api(csic, oracle):
+    """csic_multi_*: stripes over a device list from one process (device 0 listed several times here; the
+    driver's 8-GPU node is where the list has eight distinct entries)."""
+    import torch
+    W, H = 512, 300
+    argb = oracle.synth_frame(W * H, 55).reshape(H, W)
+    for (a, b, f, op, ndev) in [(2, 0, 2, CSQ, 3), (2, 0, 1, CSQ, 2), (1, 1, 4, (1, 2, 3), 4), (2, 0, 8, CSQ, 8)]:
+        want = oracle.process(_oparams(oracle, W, H, a, b, (3, 3, 2), f, op), argb)
+        cp = csic.make_c_params(W, H, a, b, 3, 3, 2, f, op)
+        with csic.MultiDeviceCompressor(cp, [0] * ndev) as md:
+            assert sum(s.nrows for s in md.stripes) == H
+            assert np.array_equal(md.process_host(argb), want), (a, b, f, op, ndev)
+            d_ins = [torch.from_numpy(argb[s.row0:s.row0 + s.nrows].view(np.int32).copy()).cuda() for s in md.stripes]
+            outs = md.process_device(d_ins)
+            md.synchronize()
+            got = np.concatenate([o.cpu().numpy().view(np.uint32) for o in outs], 0)
+            assert np.array_equal(got, want)
+    with pytest.raises(csic.CsicRuntimeError):
+        csic.MultiDeviceCompressor(csic.make_c_params(64, 64, 4, 4, 8, 8, 8, 1, CSQ), [0, 99])
