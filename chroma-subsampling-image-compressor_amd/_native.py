@@ -82,6 +82,7 @@ PROTOTYPES = {
     "csic_process_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "csic_process_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "csic_synth_frame_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]),
+    "csic_copy_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "csic_checksum_device": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64), C.c_void_p]),
     "csic_png_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "csic_png_read_argb": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t]),

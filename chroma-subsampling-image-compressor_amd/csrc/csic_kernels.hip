@@ -559,6 +559,13 @@ __global__ void __launch_bounds__(256) k_synth(uint32_t *dst, int64_t npix, int6
         dst[i] = 0xFF000000u | (fmix32((uint32_t)(first_index + i) + salt) & 0x00FFFFFFu);
 }
 
+// plain 16 B/lane non-temporal copy: the streaming ceiling bench.py quotes next to the roofline
+__global__ void __launch_bounds__(256) k_copy(const uint32_t *src, uint32_t *dst, int64_t n4)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) st4<true>(dst + 4 * i, ld4<true>(src + 4 * i));
+}
+
 __global__ void __launch_bounds__(256) k_checksum(const uint32_t *src, int64_t npix, unsigned long long *sum)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -960,6 +967,22 @@ int csic_synth_frame_device(void *d_dst, int64_t npix, int64_t first_index, uint
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
                        static_cast<uint32_t *>(d_dst), npix, first_index, seed * 0x9E3779B9u);
+    HIP_TRY(hipGetLastError());
+    clear_error();
+    return CSIC_OK;
+}
+
+int csic_copy_device(void *d_dst, const void *d_src, int64_t npix, void *hip_stream)
+{
+    if (!d_dst || !d_src) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
+    if (npix < 0 || (npix & 3) || ((((uintptr_t)d_dst) | ((uintptr_t)d_src)) & 15u))
+        return set_error(CSIC_EINVAL_SIZE, "csic_copy_device needs npix %% 4 == 0 and 16-byte aligned pointers");
+    if (npix == 0) return CSIC_OK;
+    const int64_t n4 = npix / 4, blocks = (n4 + 255) / 256;
+    if (blocks > 0x7FFFFFFF) return set_error(CSIC_EINVAL_SIZE, "copy too large for one launch");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       static_cast<const uint32_t *>(d_src), static_cast<uint32_t *>(d_dst), n4);
     HIP_TRY(hipGetLastError());
     clear_error();
     return CSIC_OK;

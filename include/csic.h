@@ -203,6 +203,11 @@ int  csic_process_host(csic_plan *plan, const uint32_t *in, size_t in_px, uint32
 int  csic_synth_frame_device(void *d_dst, int64_t npix, int64_t first_index, uint32_t seed,
                              void *hip_stream);
 
+/* Plain device-to-device copy of npix pixels with 16-byte-per-lane non-temporal accesses: the measured
+ * streaming ceiling that bench.py reports next to the spec-peak roofline.  npix % 4 == 0,
+ * 16-byte aligned pointers; asynchronous on `hip_stream`. */
+int  csic_copy_device(void *d_dst, const void *d_src, int64_t npix, void *hip_stream);
+
 /* 64-bit order-sensitive checksum of npix pixels in device memory (sum of fmix32-mixed
  * (pixel, index) pairs), for the full-size parity properties; synchronous. */
 int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *hip_stream);

@@ -595,3 +595,33 @@ def test_single_process_multi_device_api(csic, oracle):
             assert np.array_equal(got, want)
     with pytest.raises(csic.CsicRuntimeError):
         csic.MultiDeviceCompressor(csic.make_c_params(64, 64, 4, 4, 8, 8, 8, 1, CSQ), [0, 99])
+
+
+def test_deterministic_parity_frames(csic, oracle):
+    """SURVEY.md 8(d) parity frames: all-0, all-255, the five primaries tiled, and the x/y ramp that makes
+    hold and decimation phase errors visible (R = x & 255, G = y & 255, B = ((x + y) >> 1) & 255)."""
+    W, H = 520, 264
+    yy, xx = np.mgrid[0:H, 0:W]
+    prim = np.array([0x000000, 0xFFFFFF, 0xFF0000, 0x00FF00, 0x0000FF], np.uint32)
+    frames = {
+        "zeros": np.zeros((H, W), np.uint32),
+        "ones": np.full((H, W), 0xFFFFFFFF, np.uint32),
+        "primaries": (0xFF000000 | prim[(xx // 8 + yy // 8) % 5]).astype(np.uint32),
+        "ramp": (0xFF000000 | ((xx & 255) << 16) | ((yy & 255) << 8) | (((xx + yy) >> 1) & 255)).astype(np.uint32),
+    }
+    for name, fr in frames.items():
+        for (a, b), f, op in itertools.product([(4, 4), (2, 2), (2, 0), (1, 1)], (1, 2, 4, 8), [(3, 1, 2), (1, 2, 3)]):
+            want = oracle.process(_oparams(oracle, W, H, a, b, (8, 8, 8), f, op), fr, form="closed")
+            with _plan(csic, W, H, a, b, (8, 8, 8), f, op) as pl:
+                assert np.array_equal(pl.process_host(fr), want), (name, pl.kernel_name)
+
+
+def test_copy_device_utility(csic):
+    import torch
+    a = torch.randint(-2 ** 31, 2 ** 31 - 1, (1 << 20,), dtype=torch.int32, device="cuda:0")
+    b = torch.zeros_like(a)
+    sh = C.c_void_p(torch.cuda.current_stream(0).cuda_stream)
+    csic._native.check(csic._native.lib().csic_copy_device(C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), a.numel(), sh))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert csic._native.lib().csic_copy_device(C.c_void_p(b.data_ptr() + 4), C.c_void_p(a.data_ptr()), 8, sh) == csic._native.EINVAL_SIZE
