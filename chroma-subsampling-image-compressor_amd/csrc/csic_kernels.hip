@@ -11,17 +11,24 @@
 // one whose chroma is held), so the stream is embarrassingly parallel; the kernels are HBM-bound
 // integer/byte work -- no MFMA, no LDS staging (there is no reuse to stage).
 //
-// Kernel families (all written for wave64, 256-thread blocks laid out bx * by):
-//   k_f1x4   : factor 1, width % 4 == 0.  One lane = 4 consecutive pixels = one 16-byte load and one
-//              16-byte store; held chroma is reused inside the lane (h in {2,4} divides 4), the
-//              4:2:0 odd-row quirk costs one extra (row-uniform) 4-byte load.
-//   k_dec    : factor 2/4/8, chroma before spatial.  Only rows r % f == 0 are touched.  One lane = K
-//              output pixels spaced by the block width, so that every load and store instruction is
-//              lane-contiguous in the OUTPUT (loads stride f*4 bytes across lanes, stores are dense).
-//   k_dec2v  : factor 2 variants with 16-byte loads (A/B candidates for the headline config).
-//   k_generic: one lane = one output pixel, run-time parameters; covers spatial-before-chroma
-//              (chroma counters run on the decimated stream modulo the FULL width,
-//              ImageCompressorTop.scala:52-58) and widths that are not a multiple of 4.
+// Kernel families (all written for wave64; 256-thread blocks laid out bx * by, bx chosen so that rows tile
+// exactly whenever possible):
+//   k_dec    : the workhorse.  One lane = K (= 4) output pixels spaced by the block width, so every load
+//              and store instruction is lane-contiguous in the OUTPUT (4-byte nt loads with stride f*4
+//              bytes across lanes, dense 4-byte nt stores); only rows r % f == 0 are touched.  The in-row
+//              chroma hold is a DPP quad_perm on the loaded pixel, the 4:x:0 / spatial-before-chroma
+//              "replay one pixel for the whole row" cases a per-row broadcast.  Serves f = 2/4/8 in both
+//              order classes (spatial-before-chroma when f | W and h | Wo) and f = 1 for 4:x:0, any width
+//              and pointers that are only 4-byte aligned.
+//   k_f1x4   : factor 1, width % 4 == 0, v = 1.  One lane = 4 consecutive pixels = one 16-byte nt load and
+//              one 16-byte nt store; held chroma is reused inside the lane (h in {2,4} divides 4).
+//   k_dec2v  : factor 2 variants with 16-byte loads (tuning knob, not the default).
+//   k_generic: one lane = one output pixel, run-time parameters, SURVEY.md App. A.3/A.4 verbatim: the
+//              remaining spatial-before-chroma shapes (chroma counters run on the decimated stream
+//              modulo the FULL width, ImageCompressorTop.scala:52-58), frames narrower than a quad, and a
+//              YCbCr input stream (single-stage driving, the reference's spec style).
+//   k_avg / k_avg_generic : the AVG sampling EXTENSION (box-filter chroma + average pooling) -- not
+//              reference semantics, never the default; see the section comment further down.
 //
 // Citations are relative to /root/reference/.
 #include <hip/hip_runtime.h>
