@@ -30,14 +30,15 @@ def counter_means(d, counter):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     config = sys.argv[2] if len(sys.argv) > 2 else "cfg4"
-    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}" + ("" if config == "cfg4" else f"_{config}"))
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
+    sfx = "" if config == "cfg4" else f"_{config}"
     for path in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copyfile(path, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+        shutil.copyfile(path, os.path.join(dst, f"{tag}{sfx}_kernel_stats.csv"))
     for name in ("trace_bench.json", "fetch_bench.json", "write_bench.json"):
         if os.path.exists(os.path.join(src, name)):
-            shutil.copyfile(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
+            shutil.copyfile(os.path.join(src, name), os.path.join(dst, f"{tag}{sfx}_{name}"))
     fetch = counter_means(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
     write = counter_means(os.path.join(src, "pmc_write"), "WRITE_SIZE")
     cfetch = counter_means(os.path.join(src, "calib_fetch"), "FETCH_SIZE")
@@ -48,7 +49,7 @@ def main():
                                "launches": fetch.get(k, write.get(k))[1]}
     for k in sorted(set(cfetch) | set(cwrite)):
         summary["calibration"][k] = {"FETCH_SIZE_mean": cfetch.get(k, (None, 0))[0], "WRITE_SIZE_mean": cwrite.get(k, (None, 0))[0]}
-    with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as fh:
+    with open(os.path.join(dst, f"{tag}{sfx}_pmc_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
     print(json.dumps(summary, indent=1))
 

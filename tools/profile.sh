@@ -4,14 +4,17 @@
 # Outputs land in gpurun_out/prof_TAG/; tools/pmc_traffic.py condenses them into profiles/.
 set -o pipefail
 TAG=${1:-r01}
+CONFIG=${2:-cfg4}            # bench.py --config; the per-config outputs go to prof_TAG (cfg4) or prof_TAG_CONFIG
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
+if [ "$CONFIG" != "cfg4" ]; then OUT=${OUT}_$CONFIG; fi
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 # the kernel trace runs bench.py exactly as the driver does (defaults); the PMC passes skip the CPU baseline
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 $ROOT/bench.py > "$OUT/trace_bench.json" 2> "$OUT/trace.err" &&
+BENCH="python3 $ROOT/bench.py --config $CONFIG --no-cpu-baseline"
+if [ "$CONFIG" = "cfg4" ]; then TRACE="python3 $ROOT/bench.py"; else TRACE="$BENCH"; fi
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $TRACE > "$OUT/trace_bench.json" 2> "$OUT/trace.err" &&
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- $BENCH > "$OUT/fetch_bench.json" 2> "$OUT/fetch.err" &&
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- $BENCH > "$OUT/write_bench.json" 2> "$OUT/write.err" &&
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/calib_fetch" -o fetch -- python3 $ROOT/tools/pmc_calib.py > "$OUT/calib_fetch.log" 2>&1 &&
