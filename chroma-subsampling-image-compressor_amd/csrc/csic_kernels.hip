@@ -104,26 +104,27 @@ __device__ __forceinline__ uint32_t fwd_y(uint32_t px)
     return __builtin_amdgcn_udot4(px, 0x004D961Du /* A:0 R:77 G:150 B:29 */, 128u, false) >> 8;
 }
 
-// Cb/Cr.  Both coefficient rows sum to zero, so biasing every byte by -128 (px ^ 0x80808080 read as
-// i8) does not change the dot product; the +128 coefficient does not fit i8, so the row is negated:
-//   -cbI = 43R' + 85G' - 128B'      -crI = -128R' + 107G' + 21B'
-// FLOOR: ((cbI + 128) >> 8) + 128 == (cbI + 32896) >> 8 (argument always positive); the only clamp
-// that can fire is 256 -> 255.  TRUNC: Scala's '/' rounds toward zero.
+// Cb/Cr with the UNSIGNED dot product.  The negatively weighted bytes are complemented first
+// (-43 R = 43 (255 - R) - 43*255), which turns every coefficient into a u8 and moves the sign into a constant:
+//   cbI = -43R - 85G + 128B = udot4(px ^ 0x00FFFF00, {R:43, G:85, B:128}) - 32640
+//   crI = 128R - 107G - 21B = udot4(px ^ 0x0000FFFF, {R:128, G:107, B:21}) - 32640
+// FLOOR: ((cbI + 128) >> 8) + 128 == (cbI + 32896) >> 8 == (udot + 256) >> 8, with the +256 riding in the
+// dot's accumulator: xor, v_dot4_u32_u8, shift, min -- 4 VALU ops per channel (the signed v_dot4c_i32_i8
+// form needs an accumulator-init move and a subtract on top).  The only clamp that can fire is 256 -> 255
+// (SURVEY.md App. A.1).  TRUNC (Scala's '/' rounds toward zero): negative numerators cbI + 128 < 0, i.e.
+// udot < 32512, round up instead: (udot + 511) >> 8.
 template <int ROUND>
 __device__ __forceinline__ void fwd_c(uint32_t px, uint32_t &cb, uint32_t &cr)
 {
-    const int sx = (int)(px ^ 0x80808080u);
-    const int ncb = __builtin_amdgcn_sdot4(sx, (int)0x002B5580 /* A:0 R:43  G:85  B:-128 */, 0, false);
-    const int ncr = __builtin_amdgcn_sdot4(sx, (int)0x00806B15 /* A:0 R:-128 G:107 B:21  */, 0, false);
+    const uint32_t ub = __builtin_amdgcn_udot4(px ^ 0x00FFFF00u, 0x002B5580u /* A:0 R:43  G:85  B:128 */, 256u, false);
+    const uint32_t ur = __builtin_amdgcn_udot4(px ^ 0x0000FFFFu, 0x00806B15u /* A:0 R:128 G:107 B:21  */, 256u, false);
     if (ROUND == R_FLOOR) {
-        cb = (uint32_t)min((32896 - ncb) >> 8, 255);
-        cr = (uint32_t)min((32896 - ncr) >> 8, 255);
+        cb = min(ub >> 8, 255u);
+        cr = min(ur >> 8, 255u);
     } else {
-        int tb = 128 - ncb, tr = 128 - ncr;             // cbI + 128, crI + 128
-        tb += (tb >> 31) & 255;                         // trunc toward zero == floor after +255 if negative
-        tr += (tr >> 31) & 255;
-        cb = (uint32_t)min((tb >> 8) + 128, 255);
-        cr = (uint32_t)min((tr >> 8) + 128, 255);
+        // ub, ur carry the +256 already: the "negative numerator" test is udot + 256 < 32768
+        cb = min((ub + (ub < 32768u ? 255u : 0u)) >> 8, 255u);
+        cr = min((ur + (ur < 32768u ? 255u : 0u)) >> 8, 255u);
     }
 }
 
@@ -722,10 +723,10 @@ static void select_rf(csic_plan *pl)
         }
         return;
     }
-    // f = 1: the 16-byte kernel wins for v = 1 (8192^2 4:4:4: 84.1 vs 88.0 us); for 4:x:0 the 4-byte k_dec<f1>
-    // with its per-row broadcast wins (86.2 vs 89-91 us), unless the frame is too narrow for it.
+    // f = 1: the 16-byte kernel wins whenever it applies (8192^2: 4:4:4 84.0 vs 88.0 us, 4:2:0 84.5 vs 85.9 us for
+    // the 4-byte k_dec<f1>, which serves the other widths / alignments; variant 4 forces k_dec<f1> for A/B).
     const bool f1x4_ok = !pl->force_generic && !ycc_in && !pl->no_vec && g.f == 1 && g.W % 4 == 0;
-    if (f1x4_ok && (g.v == 1 || pl->variant == 3 || !dec_fast_ok(g))) {
+    if (f1x4_ok && (pl->variant != 4 || !dec_fast_ok(g))) {
         pl->fam = FAM_F1X4;
         pl->fn = nt ? pick_f1x4<ROUND, FMT, true>(g.h, g.v) : pick_f1x4<ROUND, FMT, false>(g.h, g.v);
         pl->units_per_row = g.W / 4;

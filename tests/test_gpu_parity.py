@@ -71,7 +71,7 @@ def test_random_shapes_vs_oracle(csic, oracle, seed):
             seen.add(pl.kernel_name.split("<")[0])
             got = pl.process_host(argb)
             assert np.array_equal(got, want), (pl.kernel_name, W, H, a, b, bits, f, op, rounding, fmt)
-            for variant in (1, 2, 3):                   # 16-byte-load variants (3 = k_f1x4 also for 4:x:0)
+            for variant in (1, 2, 4):                   # 16-byte-load f=2 variants; 4 = k_dec<f1> instead of k_f1x4
                 pl.tune(csic._native.TUNE_VARIANT, variant)
                 assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
             pl.tune(csic._native.TUNE_VARIANT, 0)

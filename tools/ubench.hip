@@ -240,6 +240,17 @@ __global__ void __launch_bounds__(256) k_e12(KArgs a)
     for (int k = 0; k < K; ++k) st_pol<POL>(op + co0 + k * 256, pix<true>(px[k], a));
 }
 
+// E13: memory shape of the AVG f=2 kernel (2 rows x 16 B in, 8 B out per lane) without the arithmetic
+__global__ void __launch_bounds__(256) k_e13(KArgs a)
+{
+    const int x4 = blockIdx.x * 256 + threadIdx.x;
+    const int tr = blockIdx.y;
+    const u32x4 p = ld4<true>(a.in + (int64_t)(tr * 2) * a.W + 4 * x4);
+    const u32x4 q = ld4<true>(a.in + (int64_t)(tr * 2 + 1) * a.W + 4 * x4);
+    const u32x2 o = {p.x ^ p.y ^ q.x ^ q.y, p.z ^ p.w ^ q.z ^ q.w};
+    st2<true>(a.out + (int64_t)tr * a.Wo + 2 * x4, o);
+}
+
 struct Bench {
     int W = 8192, H = 8192, Wo = 4096, Ho = 4096;
     int nring = 6, iters = 60;
@@ -392,5 +403,15 @@ int main()
     B.run("E12 store sc0 sc1 nt   grid 4x4096", L((k_e12<4, 4>), dim3(4, 4096), dim3(256)));
     B.run("E12 store plain        grid 4x4096", L((k_e12<4, 5>), dim3(4, 4096), dim3(256)));
     B.run("E12 store nt (again)   grid 4x4096", L((k_e12<4, 0>), dim3(4, 4096), dim3(256)));
+
+    {
+        KArgs proto = B.base; proto.bdx = 256; proto.bdy = 1; proto.row_step = 4096;
+        auto aa = [&](int i) { KArgs a = proto; a.in = B.in[i]; a.out = B.out[i]; return a; };
+        const double byavg = 4.0 * 8192 * 8192 + 4.0 * 4096 * 4096;
+        B.run("E13 avg-f2 memory shape only  grid 8x4096", [&](int i) { hipLaunchKernelGGL(k_e13, dim3(8, 4096), dim3(256), 0, 0, aa(i)); }, byavg);
+        B.run("shipped k_avg f2 h2 v2 nt     grid 8x4096", [&](int i) { hipLaunchKernelGGL((k_avg<R_FLOOR, F_ARGB, 2, 2, 2, true>), dim3(8, 4096), dim3(256), 0, 0, aa(i)); }, byavg);
+        B.run("shipped k_avg f2 h1 v1 nt     grid 8x4096", [&](int i) { hipLaunchKernelGGL((k_avg<R_FLOOR, F_ARGB, 2, 1, 1, true>), dim3(8, 4096), dim3(256), 0, 0, aa(i)); }, byavg);
+        B.run("shipped k_avg f2 h2 v2 ycc nt grid 8x4096", [&](int i) { hipLaunchKernelGGL((k_avg<R_FLOOR, F_YCC, 2, 2, 2, true>), dim3(8, 4096), dim3(256), 0, 0, aa(i)); }, byavg);
+    }
     return 0;
 }
