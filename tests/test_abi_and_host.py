@@ -253,3 +253,28 @@ def test_stage_generators_requires():
             S.ColorQuantizer(*bad)
     ycc = csic.pack_ycc([[1, 2]], [[3, 4]], [[5, 6]])
     assert [c.tolist() for c in csic.unpack_ycc(ycc)] == [[[1, 2]], [[3, 4]], [[5, 6]]]
+
+
+def test_last_error_is_thread_local():
+    """include/csic.h: csic_last_error() is per thread."""
+    import threading
+    lib = N.lib()
+    bad = csic.make_c_params(16, 16, 4, 4, 8, 8, 8, 3, CSQ)
+    good = csic.make_c_params(16, 16, 4, 4, 8, 8, 8, 2, CSQ)
+    seen = {}
+    gate_a, gate_b = threading.Event(), threading.Event()
+
+    def a():
+        assert lib.csic_validate(C.byref(bad)) == N.EINVAL_FACTOR
+        gate_a.set(); gate_b.wait(5)
+        seen["a"] = lib.csic_last_error()
+
+    def b():
+        gate_a.wait(5)
+        assert lib.csic_validate(C.byref(good)) == 0
+        seen["b"] = lib.csic_last_error()
+        gate_b.set()
+
+    ta, tb = threading.Thread(target=a), threading.Thread(target=b)
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert b"factor must be" in seen["a"] and seen["b"] == b""

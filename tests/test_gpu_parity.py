@@ -625,3 +625,31 @@ def test_copy_device_utility(csic):
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     assert csic._native.lib().csic_copy_device(C.c_void_p(b.data_ptr() + 4), C.c_void_p(a.data_ptr()), 8, sh) == csic._native.EINVAL_SIZE
+
+
+def test_distinct_plans_from_distinct_threads(csic, oracle):
+    """include/csic.h threading contract: a plan is single-threaded, but distinct plans may run concurrently
+    from distinct threads (ctypes releases the GIL around every call)."""
+    import threading
+    shapes = [(640, 360, 2, 0, 2), (512, 512, 2, 2, 1), (960, 540, 1, 1, 4), (1000, 100, 2, 0, 1)]
+    errors = []
+
+    def worker(k):
+        try:
+            W, H, a, b, f = shapes[k]
+            argb = oracle.synth_frame(W * H, 1000 * k)
+            want = oracle.process(_oparams(oracle, W, H, a, b, (3, 3, 2), f), argb)
+            with _plan(csic, W, H, a, b, (3, 3, 2), f) as pl:
+                for _ in range(25):
+                    if not np.array_equal(pl.process_host(argb), want):
+                        errors.append((k, "mismatch"))
+                        return
+        except Exception as exc:                      # noqa: BLE001
+            errors.append((k, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(shapes))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
