@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Randomised differential run: the HIP path (through the C ABI) against the CPU oracle on fresh seeds.
+    python tools/fuzz_gpu.py [seconds] [seed]
+Covers every kernel family, both samplings, both input formats, tuning knobs, odd shapes and batches.
+This is a TOOL for hunting corner cases on the GPU box; the fixed-seed versions live in tests/."""
+import itertools
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import csic_amd as csic
+from oracle import oracle as orc
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+rng = np.random.default_rng(seed)
+ORDERS = list(itertools.permutations((1, 2, 3)))
+MODES = [(4, 4), (2, 2), (2, 0), (1, 1), (4, 0), (1, 0)]
+N = csic._native
+t_end, n, families = time.time() + budget, 0, {}
+while time.time() < t_end:
+    kind = rng.random()
+    if kind < 0.15:
+        W, H = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+    elif kind < 0.6:
+        W, H = int(rng.integers(1, 400)), int(rng.integers(1, 120))
+    else:
+        W, H = int(rng.integers(1, 130)) * int(rng.choice([4, 8, 16])), int(rng.integers(1, 40)) * int(rng.choice([1, 2, 8]))
+    a, b = MODES[int(rng.integers(0, 6))]
+    f = int(rng.choice([1, 2, 4, 8]))
+    bits = tuple(int(x) for x in rng.integers(1, 9, 3))
+    rounding, fmt = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    avg = rng.random() < 0.25
+    op = (3, 1, 2) if avg else ORDERS[int(rng.integers(0, 6))]
+    ycc_in = rng.random() < 0.15
+    frame = rng.integers(0, 1 << 32, W * H, dtype=np.uint32)
+    if rng.random() < 0.2:                                   # low-entropy frames hit the clamps more often
+        frame = rng.choice(np.array([0, 0xFFFFFFFF, 0xFFFF0000, 0xFF00FF00, 0xFF0000FF, 0xFF00FFFF], np.uint32), W * H)
+    op_ = orc.OracleParams(width=W, height=H, chroma_a=a, chroma_b=b, y_bits=bits[0], cb_bits=bits[1], cr_bits=bits[2],
+                           factor=f, op=op, rounding=rounding, out_format=fmt, in_format=1 if ycc_in else 0)
+    want = orc.process(op_, frame, "avg" if avg else ("stream" if rng.random() < 0.5 else "closed"))
+    cp = csic.make_c_params(W, H, a, b, *bits, f, op, rounding=rounding, out_format=fmt,
+                            sampling=1 if avg else 0, in_format=1 if ycc_in else 0)
+    with csic.Plan(cp, 0) as pl:
+        knobs = [(None, None), (N.TUNE_NONTEMPORAL, 0), (N.TUNE_NO_VECTOR, 1), (N.TUNE_VARIANT, int(rng.integers(1, 5))),
+                 (N.TUNE_FORCE_GENERIC, 1)]
+        for knob, val in knobs[: 1 + int(rng.integers(0, len(knobs)))]:
+            if knob is not None:
+                pl.tune(knob, val)
+            got = pl.process_host(frame)
+            fam = pl.kernel_name.split("<")[0]
+            families[fam] = families.get(fam, 0) + 1
+            if not np.array_equal(got, want):
+                bad = np.argwhere(got != want)
+                print(f"MISMATCH seed={seed} case={n} {pl.kernel_name} W={W} H={H} a={a} b={b} bits={bits} f={f} op={op} "
+                      f"rounding={rounding} fmt={fmt} avg={avg} ycc_in={ycc_in} knob={knob}={val} first_bad={bad[0].tolist()} "
+                      f"count={len(bad)}")
+                sys.exit(1)
+    n += 1
+print(f"fuzz ok: seed {seed}, {n} cases, launches per family {families}")
