@@ -16,7 +16,6 @@ from typing import Dict, List
 
 import numpy as np
 
-from . import _native as N
 from .compressor import ImageCompressorTop
 from .model import Image, ImageProcessorModel
 from .params import ProcessingStep

@@ -13,7 +13,7 @@ the launch goes to torch's current stream.  numpy inputs take csic_process_host 
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Tuple
 
 import numpy as np
 

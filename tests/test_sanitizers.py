@@ -4,8 +4,6 @@ import glob
 import os
 import subprocess
 
-import numpy as np
-
 from conftest import GOLDEN, ROOT
 
 PKG = os.path.join(ROOT, "chroma-subsampling-image-compressor_amd")
