@@ -388,22 +388,13 @@ __global__ void __launch_bounds__(256) k_dec2v(KArgs a)
 // f <= 4 lies inside one lane's registers -- no LDS line buffer and no cross-lane traffic is needed.
 // f = 8 spans two lanes: each sums its 4 x 8 half and the halves meet through one DPP quad_perm swap.
 // ------------------------------------------------------------------------------------------------
-template <int ROUND, int FMT, int F, int HH, int VV, bool NT>
-__global__ void __launch_bounds__(256) k_avg(KArgs a)
+// arithmetic + stores of one already loaded 4 x TH tile
+template <int ROUND, int FMT, int F, int HH, int VV, bool NT, int TH>
+__device__ __forceinline__ void avg_tile(const KArgs &a, const u32x4 (&p)[TH], uint32_t *out, int tr, int x4)
 {
-    constexpr int TH = (F > VV) ? F : VV;               // tile rows per lane
     constexpr int NLOG = (HH == 4 ? 2 : HH == 2 ? 1 : 0) + (VV == 2 ? 1 : 0);
     constexpr int FLOG2 = (F == 8 ? 6 : F == 4 ? 4 : F == 2 ? 2 : 0);
-    pin_args(a);
-    const int x4 = blockIdx.x * a.bdx + threadIdx.x;
-    if (x4 >= (a.W >> 2)) return;
-    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
-    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
-    const int ntr = a.H / TH;
-    for (int tr = blockIdx.y * a.bdy + threadIdx.y; tr < ntr; tr += a.row_step) {
-        u32x4 p[TH];
-#pragma unroll
-        for (int i = 0; i < TH; ++i) p[i] = ld4<NT>(in + (int64_t)(tr * TH + i) * a.W + 4 * x4);
+    {
         uint32_t Y[TH][4], Cb[TH][4], Cr[TH][4];
 #pragma unroll
         for (int i = 0; i < TH; ++i) {
@@ -473,6 +464,35 @@ __global__ void __launch_bounds__(256) k_avg(KArgs a)
                 sr = ((sr + 32) >> 6) & a.mcr;
                 st1<NT>(out + (int64_t)tr * a.Wo + (x4 >> 1), finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr)));
             }
+        }
+    }
+}
+
+// TILES column groups per lane, spaced by the block width: all TILES * TH loads are issued before the first
+// tile's arithmetic starts, so one tile's ~170 VALU ops overlap the other tiles' memory latency.
+template <int ROUND, int FMT, int F, int HH, int VV, bool NT, int TILES = (F <= 2 ? 2 : 1)>
+__global__ void __launch_bounds__(256) k_avg(KArgs a)
+{
+    constexpr int TH = (F > VV) ? F : VV;               // tile rows per lane
+    pin_args(a);
+    const int W4 = a.W >> 2;
+    const int x0 = blockIdx.x * (a.bdx * TILES) + threadIdx.x;
+    if (x0 >= W4) return;
+    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
+    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const int ntr = a.H / TH;
+    for (int tr = blockIdx.y * a.bdy + threadIdx.y; tr < ntr; tr += a.row_step) {
+        u32x4 p[TILES][TH];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const int x4 = min(x0 + t * a.bdx, W4 - 1);        // clamp: out-of-row tiles re-read the last one
+#pragma unroll
+            for (int i = 0; i < TH; ++i) p[t][i] = ld4<NT>(in + (int64_t)(tr * TH + i) * a.W + 4 * x4);
+        }
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const int x4 = x0 + t * a.bdx;
+            if (TILES == 1 || x4 < W4) avg_tile<ROUND, FMT, F, HH, VV, NT, TH>(a, p[t], out, tr, x4);
         }
     }
 }
@@ -712,7 +732,7 @@ static void select_rf(csic_plan *pl)
             pl->fam = FAM_AVG;
             pl->fn = nt ? pick_avg<ROUND, FMT, true>(g.f, g.h, g.v) : pick_avg<ROUND, FMT, false>(g.f, g.h, g.v);
             pl->units_per_row = g.W / 4;
-            pl->k_per_lane = 1;
+            pl->k_per_lane = (g.f <= 2) ? 2 : 1;          // TILES of k_avg
             snprintf(pl->name, sizeof pl->name, "k_avg<%s,%s,f%d,h%d,v%d,%s>", rn, fn, g.f, g.h, g.v, ntn);
         } else {
             pl->fam = FAM_AVG_GENERIC;
