@@ -11,8 +11,8 @@ from .params import ImageProcessorParams, PixelFormat, ProcessingStep, Rounding,
 from .compressor import ImageCompressorTop, ImageProcessor, Plan
 from .model import Image, ImageProcessorModel
 from .pipeline import FramePipeline
-from .stages import (ChromaSubsampler, ColorQuantizer, ReferenceModel, RGB2YCbCr, SpatialDownsampler, YCbCrUtils,
-                     pack_ycc, unpack_ycc)
+from .stages import (ChromaSubsampler, ColorQuantizer, PixelBundle, PixelYCbCrBundle, ReferenceModel, RGB2YCbCr,
+                     SpatialDownsampler, YCbCrUtils, pack_ycc, unpack_ycc)
 from .app import ImageCompressionApp
 from .distributed import MultiDeviceCompressor, Stripe, StripedImageCompressorTop, halo_stripe_for_rank, stripe_for_rank
 from . import app, compressor, distributed, model, params, pipeline, stages
@@ -20,6 +20,6 @@ from . import app, compressor, distributed, model, params, pipeline, stages
 __all__ = [
     "CsicIOError", "CsicRuntimeError", "IllegalArgumentException", "ImageProcessorParams", "PixelFormat", "ProcessingStep",
     "Rounding", "Sampling", "make_c_params", "ImageCompressorTop", "ImageProcessor", "Plan", "Image", "ImageProcessorModel",
-    "ImageCompressionApp", "FramePipeline", "ChromaSubsampler", "ColorQuantizer", "ReferenceModel", "RGB2YCbCr",
+    "ImageCompressionApp", "FramePipeline", "ChromaSubsampler", "ColorQuantizer", "PixelBundle", "PixelYCbCrBundle", "ReferenceModel", "RGB2YCbCr",
     "SpatialDownsampler", "YCbCrUtils", "pack_ycc", "unpack_ycc", "Stripe", "StripedImageCompressorTop", "MultiDeviceCompressor", "halo_stripe_for_rank", "stripe_for_rank",
 ]

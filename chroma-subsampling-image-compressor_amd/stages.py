@@ -30,6 +30,26 @@ _CSQ = (ProcessingStep.ChromaSubsampling, ProcessingStep.SpatialSampling, Proces
 YCC, ARGB = PixelFormat.YCBCR888X, PixelFormat.ARGB8888
 
 
+# The two stream element types (PixelBundle.scala:5-9, :11-15): 3 x UInt(8) each.  On the GPU a pixel travels
+# as one uint32: PixelBundle -> ARGB8888 (0xFFRRGGBB), PixelYCbCrBundle -> YCBCR888X (Y | Cb << 8 | Cr << 16).
+class PixelBundle(namedtuple("PixelBundle", "r g b")):
+    def packed(self) -> int:
+        return 0xFF000000 | (self.r & 0xFF) << 16 | (self.g & 0xFF) << 8 | (self.b & 0xFF)
+
+    @staticmethod
+    def unpack(v: int) -> "PixelBundle":
+        return PixelBundle((v >> 16) & 0xFF, (v >> 8) & 0xFF, v & 0xFF)
+
+
+class PixelYCbCrBundle(namedtuple("PixelYCbCrBundle", "y cb cr")):
+    def packed(self) -> int:
+        return (self.y & 0xFF) | (self.cb & 0xFF) << 8 | (self.cr & 0xFF) << 16
+
+    @staticmethod
+    def unpack(v: int) -> "PixelYCbCrBundle":
+        return PixelYCbCrBundle(v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF)
+
+
 def _require(cond: bool, status: int, msg: str) -> None:
     if not cond:
         raise N.IllegalArgumentException(status, "requirement failed: " + msg)

@@ -278,3 +278,11 @@ def test_last_error_is_thread_local():
     ta, tb = threading.Thread(target=a), threading.Thread(target=b)
     ta.start(); tb.start(); ta.join(); tb.join()
     assert b"factor must be" in seen["a"] and seen["b"] == b""
+
+
+def test_pixel_bundle_types():
+    """PixelBundle / PixelYCbCrBundle (PixelBundle.scala:5-15) and their packed uint32 forms."""
+    p = csic.PixelBundle(1, 2, 3)
+    assert p.packed() == 0xFF010203 and csic.PixelBundle.unpack(0x80AABBCC) == (0xAA, 0xBB, 0xCC)
+    y = csic.PixelYCbCrBundle(16, 128, 240)
+    assert y.packed() == 16 | 128 << 8 | 240 << 16 and csic.PixelYCbCrBundle.unpack(y.packed()) == y
