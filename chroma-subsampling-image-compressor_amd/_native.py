@@ -80,6 +80,7 @@ PROTOTYPES = {
     "csic_plan_tune": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "csic_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "csic_process_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "csic_process_pitched_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "csic_process_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "csic_synth_frame_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]),
     "csic_copy_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

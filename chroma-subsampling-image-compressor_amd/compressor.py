@@ -99,6 +99,21 @@ class Plan:
         N.check(st)
         return d_out
 
+    def process_device_pitched(self, d_in, in_pitch_px: int, d_out, out_pitch_px: int, nframes: int = 1,
+                               in_offset_px: int = 0, out_offset_px: int = 0):
+        """Frames whose rows are not tightly packed (csic_process_pitched_device): row r starts `in_pitch_px`
+        pixels after row r-1.  `d_in` / `d_out` are 4-byte CUDA tensors that contain the (possibly padded or
+        larger) surfaces; `*_offset_px` select the first pixel, e.g. the top-left corner of a region of interest.
+        Asynchronous on torch's current stream; the caller guarantees the tensors are large enough."""
+        need_in = in_offset_px + ((nframes * self.height - 1) * in_pitch_px + self.width)
+        need_out = out_offset_px + ((nframes * self.out_height - 1) * out_pitch_px + self.out_width)
+        if d_in.numel() < need_in or d_out.numel() < need_out or d_in.element_size() != 4 or d_out.element_size() != 4:
+            raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: surface too small for the pitched frame")
+        N.check(N.lib().csic_process_pitched_device(
+            self._h, C.c_void_p(d_in.data_ptr() + 4 * in_offset_px), in_pitch_px,
+            C.c_void_p(d_out.data_ptr() + 4 * out_offset_px), out_pitch_px, nframes, self._stream()))
+        return d_out
+
     def process_host(self, argb: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(argb, dtype=np.uint32).reshape(-1)
         out = np.empty(self.out_width * self.out_height, dtype=np.uint32)

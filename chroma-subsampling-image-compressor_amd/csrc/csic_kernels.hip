@@ -54,6 +54,7 @@ struct KArgs {
     int32_t sc_shift, bc_row_off, bc_col_in;   // k_dec SROWS: log2 f; held-sample decimated row offset / input column
     int64_t in_frame_px, out_frame_px;  // batch strides (grid z = frame)
     int32_t bdx, bdy, row_step;         // block width/height and gridDim.y * bdy, passed explicitly (see pin_args)
+    int32_t ip, op;                     // row pitch of the input / output frame in pixels (>= W / Wo; == when packed)
 };
 
 // Wave prologue.  hipcc sinks every kernel-argument s_load to its first use, and blockDim/gridDim come
@@ -65,7 +66,7 @@ __device__ __forceinline__ void pin_args(const KArgs &a)
 {
     asm volatile("" ::"s"(a.in), "s"(a.out), "s"(a.W), "s"(a.H), "s"(a.Wo), "s"(a.Ho), "s"(a.last_sample_col));
     asm volatile("" ::"s"(a.my), "s"(a.mcb), "s"(a.mcr), "s"(a.in_frame_px), "s"(a.out_frame_px), "s"(a.bdx),
-                 "s"(a.bdy), "s"(a.row_step));
+                 "s"(a.bdy), "s"(a.row_step), "s"(a.ip), "s"(a.op));
 }
 
 enum { R_FLOOR = CSIC_ROUND_FLOOR_HW, R_TRUNC = CSIC_ROUND_TRUNC_SW };
@@ -209,13 +210,14 @@ __global__ void __launch_bounds__(256) k_f1x4(KArgs a)
     uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
     const int row_step = a.row_step;
     for (int row = blockIdx.y * a.bdy + threadIdx.y; row < a.H; row += row_step) {
-        const int64_t base = (int64_t)row * a.W + 4 * x4;
+        const int64_t base = (int64_t)row * a.ip + 4 * x4;
+        const int64_t obase = (int64_t)row * a.op + 4 * x4;
         // 4:x:0 odd row: no pixel is a sample point, the whole row replays the chroma latched at the last
         // sample of the previous row (ChromaSubsampler.scala:52-65).  Its load is
         // issued ahead of the 16-byte stream load so that the two latencies overlap.
         const bool odd = (VV == 2) && (row & 1);
         uint32_t cpx = 0;
-        if (odd) cpx = in[(int64_t)(row - 1) * a.W + a.last_sample_col];
+        if (odd) cpx = in[(int64_t)(row - 1) * a.ip + a.last_sample_col];
         const u32x4 p = ld4<NT>(in + base);
         const uint32_t px[4] = {p.x, p.y, p.z, p.w};
         uint32_t o[4];
@@ -232,7 +234,7 @@ __global__ void __launch_bounds__(256) k_f1x4(KArgs a)
             }
         }
         const u32x4 ov = {o[0], o[1], o[2], o[3]};
-        st4<NT>(out + base, ov);
+        st4<NT>(out + obase, ov);
     }
 }
 
@@ -302,13 +304,13 @@ __device__ __forceinline__ void dec_rows(const KArgs &a, const uint32_t *in, uin
                                          int ro0, int row_step)
 {
     for (int ro = ro0; ro < a.Ho; ro += row_step) {
-        const uint32_t *rowp = in + (int64_t)(ro * F) * a.W;
-        uint32_t *orow = out + (int64_t)ro * a.Wo;
+        const uint32_t *rowp = in + (int64_t)(ro * F) * a.ip;
+        uint32_t *orow = out + (int64_t)ro * a.op;
         if (SROWS) {
             const int r = ro >> a.sc_shift;                               // chroma row = ro / F
             if (r & a.vmask) {                                            // odd chroma row of 4:x:0
                 const int srow = ((r - 1) << a.sc_shift) + a.bc_row_off; // decimated row of the held sample
-                const uint32_t bpx = in[(int64_t)(srow * F) * a.W + a.bc_col_in];
+                const uint32_t bpx = in[(int64_t)(srow * F) * a.ip + a.bc_col_in];
                 dec_chunk<ROUND, FMT, F, HOLD, true, K, NT, CHECK>(a, rowp, orow, co0, bx, bpx);
                 continue;
             }
@@ -353,8 +355,8 @@ __global__ void __launch_bounds__(256) k_dec2v(KArgs a)
     uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
     const int row_step = a.row_step;
     for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += row_step) {
-        const uint32_t *rowp = in + (int64_t)(ro * 2) * a.W + (int64_t)x * (OPL * 2);
-        uint32_t *op = out + (int64_t)ro * a.Wo + (int64_t)x * OPL;
+        const uint32_t *rowp = in + (int64_t)(ro * 2) * a.ip + (int64_t)x * (OPL * 2);
+        uint32_t *op = out + (int64_t)ro * a.op + (int64_t)x * OPL;
         if (VAR == 1) {
             const u32x4 p = ld4<NT>(rowp);
             const ChromaTerm t0 = chroma_term<ROUND, FMT>(p.x, a.mcb, a.mcr);
@@ -443,7 +445,7 @@ __device__ __forceinline__ void avg_tile(const KArgs &a, const u32x4 (&p)[TH], u
                     sr = ((sr + ((FF * FF) >> 1)) >> FLOG2) & a.mcr;
                     o[oj] = finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr));
                 }
-                uint32_t *op = out + (int64_t)(tr * NOY + oi) * a.Wo + x4 * NOX;
+                uint32_t *op = out + (int64_t)(tr * NOY + oi) * a.op + x4 * NOX;
                 if (NOX == 4) { const u32x4 ov = {o[0], o[1 % NOX], o[2 % NOX], o[3 % NOX]}; st4<NT>(op, ov); }
                 else if (NOX == 2) { const u32x2 ov = {o[0], o[1 % NOX]}; st2<NT>(op, ov); }
                 else st1<NT>(op, o[0]);
@@ -462,7 +464,7 @@ __device__ __forceinline__ void avg_tile(const KArgs &a, const u32x4 (&p)[TH], u
                 sy = ((sy + 32) >> 6) & a.my;
                 sb = ((sb + 32) >> 6) & a.mcb;
                 sr = ((sr + 32) >> 6) & a.mcr;
-                st1<NT>(out + (int64_t)tr * a.Wo + (x4 >> 1), finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr)));
+                st1<NT>(out + (int64_t)tr * a.op + (x4 >> 1), finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr)));
             }
         }
     }
@@ -487,7 +489,7 @@ __global__ void __launch_bounds__(256) k_avg(KArgs a)
         for (int t = 0; t < TILES; ++t) {
             const int x4 = min(x0 + t * a.bdx, W4 - 1);        // clamp: out-of-row tiles re-read the last one
 #pragma unroll
-            for (int i = 0; i < TH; ++i) p[t][i] = ld4<NT>(in + (int64_t)(tr * TH + i) * a.W + 4 * x4);
+            for (int i = 0; i < TH; ++i) p[t][i] = ld4<NT>(in + (int64_t)(tr * TH + i) * a.ip + 4 * x4);
         }
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
@@ -514,14 +516,14 @@ __global__ void __launch_bounds__(256) k_avg_generic(KArgs a)
         for (int i = 0; i < f; ++i) {
             for (int j = 0; j < f; ++j) {
                 const int r = min(ro * f + i, a.H - 1), c = min(co * f + j, a.W - 1);
-                sy += in_y<ROUND, INFMT>(in[(int64_t)r * a.W + c]);
+                sy += in_y<ROUND, INFMT>(in[(int64_t)r * a.ip + c]);
                 const int r0 = r & ~a.vmask, c0 = c & ~a.hmask;
                 uint32_t ab = 0, ar = 0;
                 for (int ii = 0; ii < v; ++ii) {
                     for (int jj = 0; jj < h; ++jj) {
                         const int rr = min(r0 + ii, a.H - 1), cc = min(c0 + jj, a.W - 1);
                         uint32_t cb, cr;
-                        in_c<ROUND, INFMT>(in[(int64_t)rr * a.W + cc], cb, cr);
+                        in_c<ROUND, INFMT>(in[(int64_t)rr * a.ip + cc], cb, cr);
                         ab += cb; ar += cr;
                     }
                 }
@@ -532,7 +534,7 @@ __global__ void __launch_bounds__(256) k_avg_generic(KArgs a)
         sy = ((sy + ((f * f) >> 1)) >> flog2) & a.my;
         sb = ((sb + ((f * f) >> 1)) >> flog2) & a.mcb;
         sr = ((sr + ((f * f) >> 1)) >> flog2) & a.mcr;
-        out[(int64_t)ro * a.Wo + co] = finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr));
+        out[(int64_t)ro * a.op + co] = finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr));
     }
 }
 
@@ -549,12 +551,12 @@ __global__ void __launch_bounds__(256) k_generic(KArgs a)
     uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
     const int row_step = a.row_step;
     for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += row_step) {
-        const int64_t y_idx = (int64_t)(ro * a.f) * a.W + co * a.f;
+        const int64_t y_idx = (int64_t)(ro * a.f) * a.ip + co * a.f;
         int64_t c_idx;
         if (!a.s_first) {
             const int r = ro * a.f, c = co * a.f;       // chroma counters == image coordinates
-            c_idx = ((r & a.vmask) == 0) ? (int64_t)r * a.W + (c & ~a.hmask)
-                                         : (int64_t)(r - 1) * a.W + a.last_sample_col;
+            c_idx = ((r & a.vmask) == 0) ? (int64_t)r * a.ip + (c & ~a.hmask)
+                                         : (int64_t)(r - 1) * a.ip + a.last_sample_col;
         } else {
             // chroma sits behind the decimator but was built with the full width
             // (ImageCompressorTop.scala:52-58): its column counter wraps every W decimated pixels.
@@ -562,12 +564,12 @@ __global__ void __launch_bounds__(256) k_generic(KArgs a)
             const int r = j / a.W, c = j - r * a.W;
             const int src = ((r & a.vmask) == 0) ? (j - (c & a.hmask)) : ((r - 1) * a.W + a.last_sample_col);
             const int sro = src / a.Wo, sco = src - sro * a.Wo;
-            c_idx = (int64_t)(sro * a.f) * a.W + sco * a.f;
+            c_idx = (int64_t)(sro * a.f) * a.ip + sco * a.f;       // (counters above use the semantic W, addresses the pitch)
         }
         uint32_t cb, cr;
         in_c<ROUND, INFMT>(in[c_idx], cb, cr);
         const uint32_t y = in_y<ROUND, INFMT>(in[y_idx]) & a.my;
-        out[(int64_t)ro * a.Wo + co] = finish_y<FMT>(y, chroma_term_q<FMT>(cb & a.mcb, cr & a.mcr));
+        out[(int64_t)ro * a.op + co] = finish_y<FMT>(y, chroma_term_q<FMT>(cb & a.mcb, cr & a.mcr));
     }
 }
 
@@ -803,7 +805,8 @@ static int ensure_device(const csic_plan *pl)
     return CSIC_OK;
 }
 
-static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream)
+static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream,
+                  int32_t in_pitch = 0, int32_t out_pitch = 0)
 {
     if (!pl) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
     if (!d_in || !d_out) return set_error(CSIC_EINVAL_NULL, "device buffer is NULL");
@@ -816,8 +819,11 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
     KernelFn fn = pl->fn;
     int units = pl->units_per_row, kpl = pl->k_per_lane, dec_hold = pl->dec_hold;
     // The vector kernels need 16-byte aligned frame bases; otherwise take the 4-byte-access kernels.
+    const int32_t ip = in_pitch > 0 ? in_pitch : g.W, op = out_pitch > 0 ? out_pitch : g.Wo;
+    if (ip < g.W || op < g.Wo)
+        return set_error(CSIC_EINVAL_SIZE, "row pitch (%d, %d px) smaller than the frame width (%d, %d px)", ip, op, g.W, g.Wo);
     const bool vec = (fam == FAM_F1X4 || fam == FAM_DEC2V1 || fam == FAM_DEC2V2 || fam == FAM_AVG);
-    if (vec && ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15u)) {
+    if (vec && (((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15u) || ((ip | op) & 3))) {
         csic_plan tmp = *pl;
         tmp.no_vec = 1;
         select(&tmp);
@@ -831,8 +837,9 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
     a.last_sample_col = g.last_sample_col;
     a.my = g.mask_y; a.mcb = g.mask_cb; a.mcr = g.mask_cr;
     a.f = g.f; a.hmask = g.h - 1; a.vmask = g.v - 1; a.s_first = g.s_first;
-    a.in_frame_px = (int64_t)g.W * g.H;
-    a.out_frame_px = (int64_t)g.Wo * g.Ho;
+    a.ip = ip; a.op = op;
+    a.in_frame_px = (int64_t)ip * g.H;
+    a.out_frame_px = (int64_t)op * g.Ho;
     a.sc_shift = (g.f == 8) ? 3 : (g.f == 4) ? 2 : (g.f == 2) ? 1 : 0;
     a.bc_row_off = g.last_sample_col / g.Wo;             // only meaningful (and only used) when f | W
     a.bc_col_in = (g.last_sample_col % g.Wo) * g.f;
@@ -961,6 +968,13 @@ int csic_process_device(csic_plan *plan, const void *d_in, void *d_out, void *hi
 int csic_process_batch_device(csic_plan *plan, const void *d_in, void *d_out, int32_t nframes, void *hip_stream)
 {
     return launch(plan, d_in, d_out, nframes, static_cast<hipStream_t>(hip_stream));
+}
+
+int csic_process_pitched_device(csic_plan *plan, const void *d_in, int32_t in_pitch_px, void *d_out, int32_t out_pitch_px,
+                                int32_t nframes, void *hip_stream)
+{
+    if (in_pitch_px <= 0 || out_pitch_px <= 0) return set_error(CSIC_EINVAL_SIZE, "row pitches must be positive");
+    return launch(plan, d_in, d_out, nframes, static_cast<hipStream_t>(hip_stream), in_pitch_px, out_pitch_px);
 }
 
 int csic_process_host(csic_plan *plan, const uint32_t *in, size_t in_px, uint32_t *out, size_t out_px)

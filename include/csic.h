@@ -193,6 +193,15 @@ int  csic_process_device(csic_plan *plan, const void *d_in, void *d_out, void *h
 int  csic_process_batch_device(csic_plan *plan, const void *d_in, void *d_out, int32_t nframes,
                                void *hip_stream);
 
+/* The same for frames whose rows are NOT tightly packed: row r of frame k starts at
+ * d_in + (k * height + r) * in_pitch_px pixels (resp. out_height / out_pitch_px for the output), with
+ * in_pitch_px >= width and out_pitch_px >= out_width.  Padded decoder surfaces and regions of interest inside a
+ * larger frame go through without a repacking copy (the reference streams pixels and has no pitch notion: the
+ * semantic width -- chroma counters, ImageCompressorTop.scala:52-58 -- stays `width`; only addressing changes).
+ * The 16-byte kernels need pitches that are multiples of 4 pixels, otherwise the 4-byte kernels are used. */
+int  csic_process_pitched_device(csic_plan *plan, const void *d_in, int32_t in_pitch_px, void *d_out,
+                                 int32_t out_pitch_px, int32_t nframes, void *hip_stream);
+
 /* Convenience synchronous host path: H2D + kernel + D2H through plan-owned staging buffers.
  * in_px must equal width*height and out_px out_width*out_height. */
 int  csic_process_host(csic_plan *plan, const uint32_t *in, size_t in_px, uint32_t *out, size_t out_px);

@@ -653,3 +653,57 @@ def test_distinct_plans_from_distinct_threads(csic, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_pitched_frames_and_regions_of_interest(csic, oracle):
+    """csic_process_pitched_device: a region of interest inside a larger surface in, a padded surface out,
+    for every kernel family (incl. pitches/offsets that break 16-byte alignment -> 4-byte kernels)."""
+    import torch
+    rng = np.random.default_rng(31)
+    W0, H0 = 700, 300
+    surface = rng.integers(0, 1 << 32, (H0, W0), dtype=np.uint32)
+    d_surface = torch.from_numpy(surface.view(np.int32)).cuda()
+    cases = [  # x0, y0, W, H, a, b, f, op, sampling
+        (8, 4, 512, 128, 2, 2, 1, CSQ, 0),      # k_f1x4 (aligned ROI)
+        (8, 4, 512, 128, 2, 0, 1, CSQ, 0),
+        (3, 5, 333, 77, 2, 0, 1, CSQ, 0),       # unaligned ROI -> k_dec<f1>
+        (16, 2, 640, 200, 2, 0, 2, CSQ, 0),     # k_dec<f2>
+        (5, 1, 600, 96, 1, 1, 2, CSQ, 0),       # hold2, odd offset
+        (12, 0, 512, 128, 2, 0, 4, (1, 2, 3), 0),  # spatial before chroma fast path
+        (7, 3, 250, 50, 2, 0, 4, (1, 3, 2), 0),    # generic
+        (4, 8, 512, 64, 2, 0, 2, CSQ, 1),       # AVG fast
+        (9, 9, 301, 41, 2, 0, 4, CSQ, 1),       # AVG generic
+    ]
+    for (x0, y0, W, H, a, b, f, op, samp) in cases:
+        roi = np.ascontiguousarray(surface[y0:y0 + H, x0:x0 + W])
+        want = oracle.process(_oparams(oracle, W, H, a, b, (3, 3, 2), f, op), roi, form="avg" if samp else "closed")
+        cp = csic.make_c_params(W, H, a, b, 3, 3, 2, f, op, sampling=samp)
+        with csic.Plan(cp, 0) as pl:
+            for pad, off in ((0, 0), (4, 0), (13, 3)):
+                opitch = pl.out_width + pad
+                d_out = torch.full((pl.out_height * opitch + off + 8,), 0x5A5A5A5A, dtype=torch.int32, device="cuda:0")
+                pl.process_device_pitched(d_surface.reshape(-1), W0, d_out, opitch, in_offset_px=y0 * W0 + x0, out_offset_px=off)
+                torch.cuda.synchronize()
+                o = d_out.cpu().numpy().view(np.uint32)
+                got = o[off:off + pl.out_height * opitch].reshape(pl.out_height, opitch)
+                assert np.array_equal(got[:, :pl.out_width], want), (pl.kernel_name, x0, y0, pad, off)
+                assert np.all(got[:-1, pl.out_width:] == 0x5A5A5A5A)             # padding untouched
+                assert np.all(o[:off] == 0x5A5A5A5A)
+    with _plan(csic, 64, 64) as pl:                                              # pitch smaller than the width
+        d = torch.zeros(64 * 64, dtype=torch.int32, device="cuda:0")
+        assert csic._native.lib().csic_process_pitched_device(pl._h, C.c_void_p(d.data_ptr()), 32, C.c_void_p(d.data_ptr()), 64, 1,
+                                                              C.c_void_p(0)) == csic._native.EINVAL_SIZE
+    # two pitched frames in one launch
+    W, H, n = 256, 64, 2
+    cp = csic.make_c_params(W, H, 2, 0, 3, 3, 2, 2, CSQ)
+    with csic.Plan(cp, 0) as pl:
+        ipitch, opitch = 300, 140
+        src = rng.integers(0, 1 << 32, (n * H, ipitch), dtype=np.uint32)
+        d_in = torch.from_numpy(src.view(np.int32)).cuda().reshape(-1)
+        d_out = torch.zeros(n * pl.out_height * opitch, dtype=torch.int32, device="cuda:0")
+        pl.process_device_pitched(d_in, ipitch, d_out, opitch, nframes=n)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().view(np.uint32).reshape(n, pl.out_height, opitch)
+        for k in range(n):
+            want = oracle.process(_oparams(oracle, W, H, 2, 0, (3, 3, 2), 2), np.ascontiguousarray(src[k * H:(k + 1) * H, :W]))
+            assert np.array_equal(got[k][:, :pl.out_width], want)

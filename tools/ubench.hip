@@ -268,7 +268,7 @@ struct Bench {
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         memset(&base, 0, sizeof base);
         base.W = W; base.H = H; base.Wo = Wo; base.Ho = Ho; base.my = base.mcb = base.mcr = 0xFF;
-        base.f = 2; base.bdx = 256; base.bdy = 1; base.row_step = 8192; base.in_frame_px = (int64_t)W * H; base.out_frame_px = (int64_t)Wo * Ho;
+        base.f = 2; base.bdx = 256; base.bdy = 1; base.row_step = 8192; base.ip = W; base.op = Wo; base.in_frame_px = (int64_t)W * H; base.out_frame_px = (int64_t)Wo * Ho;
         CK(hipDeviceSynchronize());
     }
     template <class F> void run(const char *name, F launch, double bytes = 201326592.0)
@@ -362,7 +362,7 @@ int main()
     B.run("E9 f1 K2 4:4:4 nt      grid 4x8192", [&](int i) { hipLaunchKernelGGL((k_e9<2, true>), dim3(4, 8192), dim3(256), 0, 0, f1args(i)); }, 536870912.0);
     B.run("E9 f1 K4 4:4:4 nt      grid 2x8192", [&](int i) { hipLaunchKernelGGL((k_e9<4, true>), dim3(2, 8192), dim3(256), 0, 0, f1args(i)); }, 536870912.0);
     {
-        KArgs proto = B.base; proto.H = 8192; proto.Ho = 8192; proto.Wo = 8192; proto.f = 1;
+        KArgs proto = B.base; proto.H = 8192; proto.Ho = 8192; proto.Wo = 8192; proto.op = 8192; proto.f = 1;
         auto sargs = [&](int i) { KArgs a = proto; a.in = B.in[i]; a.out = B.in[(i + 1) % B.nring]; return a; };
         B.run("shipped k_f1x4 444 nt  grid 8x8192", [&](int i) { hipLaunchKernelGGL((k_f1x4<R_FLOOR, F_ARGB, 1, 1, true>), dim3(8, 8192), dim3(256), 0, 0, sargs(i)); }, 536870912.0);
         B.run("shipped k_f1x4 420 nt  grid 8x8192", [&](int i) { hipLaunchKernelGGL((k_f1x4<R_FLOOR, F_ARGB, 2, 2, true>), dim3(8, 8192), dim3(256), 0, 0, sargs(i)); }, 536870912.0);
@@ -375,7 +375,7 @@ int main()
     for (int i = 0; i < B.nring; ++i) hipLaunchKernelGGL(k_synth, dim3(8192), dim3(256), 0, 0, B.in[i], (int64_t)B.W * B.H, (int64_t)i * B.W * B.H, 20250629u * 0x9E3779B9u);
 
     {   // f = 8 on 8192x8192: Wo = Ho = 1024; algorithmic bytes = 4*8192*1024 + 4*1024*1024
-        KArgs proto = B.base; proto.Wo = 1024; proto.Ho = 1024; proto.f = 8;
+        KArgs proto = B.base; proto.Wo = 1024; proto.op = 1024; proto.Ho = 1024; proto.f = 8;
         auto a8 = [&](int i) { KArgs a = proto; a.in = B.in[i]; a.out = B.out[i]; return a; };
         const double by8 = 4.0 * 8192 * 1024 + 4.0 * 1024 * 1024;
         B.run("E11 f8 K1 dword nt   grid 4x1024", [&](int i) { hipLaunchKernelGGL((k_e11<8, 1, 1, true, true>), dim3(4, 1024), dim3(256), 0, 0, a8(i)); }, by8);
@@ -386,7 +386,7 @@ int main()
         B.run("E11 f8 K1 x4 nt      grid 4x1024", [&](int i) { hipLaunchKernelGGL((k_e11<8, 1, 4, true, true>), dim3(4, 1024), dim3(256), 0, 0, a8(i)); }, by8);
         B.run("E11 f8 K4 x4 nt      grid 1x1024", [&](int i) { hipLaunchKernelGGL((k_e11<8, 4, 4, true, true>), dim3(1, 1024), dim3(256), 0, 0, a8(i)); }, by8);
         B.run("E11 f8 K2 x4 cached  grid 2x1024", [&](int i) { hipLaunchKernelGGL((k_e11<8, 2, 4, false, true>), dim3(2, 1024), dim3(256), 0, 0, a8(i)); }, by8);
-        KArgs p4 = B.base; p4.Wo = 2048; p4.Ho = 2048; p4.f = 4;
+        KArgs p4 = B.base; p4.Wo = 2048; p4.op = 2048; p4.Ho = 2048; p4.f = 4;
         auto a4 = [&](int i) { KArgs a = p4; a.in = B.in[i]; a.out = B.out[i]; return a; };
         const double by4 = 4.0 * 8192 * 2048 + 4.0 * 2048 * 2048;
         B.run("E11 f4 K4 dword nt   grid 2x2048", [&](int i) { hipLaunchKernelGGL((k_e11<4, 4, 1, true, true>), dim3(2, 2048), dim3(256), 0, 0, a4(i)); }, by4);
