@@ -409,9 +409,9 @@ int main()
         auto aa = [&](int i) { KArgs a = proto; a.in = B.in[i]; a.out = B.out[i]; return a; };
         const double byavg = 4.0 * 8192 * 8192 + 4.0 * 4096 * 4096;
         B.run("E13 avg-f2 memory shape only  grid 8x4096", [&](int i) { hipLaunchKernelGGL(k_e13, dim3(8, 4096), dim3(256), 0, 0, aa(i)); }, byavg);
-        B.run("shipped k_avg f2 h2 v2 nt     grid 8x4096", [&](int i) { hipLaunchKernelGGL((k_avg<R_FLOOR, F_ARGB, 2, 2, 2, true>), dim3(8, 4096), dim3(256), 0, 0, aa(i)); }, byavg);
-        B.run("shipped k_avg f2 h1 v1 nt     grid 8x4096", [&](int i) { hipLaunchKernelGGL((k_avg<R_FLOOR, F_ARGB, 2, 1, 1, true>), dim3(8, 4096), dim3(256), 0, 0, aa(i)); }, byavg);
-        B.run("shipped k_avg f2 h2 v2 ycc nt grid 8x4096", [&](int i) { hipLaunchKernelGGL((k_avg<R_FLOOR, F_YCC, 2, 2, 2, true>), dim3(8, 4096), dim3(256), 0, 0, aa(i)); }, byavg);
+        B.run("shipped k_avg f2 h2 v2 nt     grid 4x4096", [&](int i) { hipLaunchKernelGGL((k_avg<R_FLOOR, F_ARGB, 2, 2, 2, true>), dim3(4, 4096), dim3(256), 0, 0, aa(i)); }, byavg);
+        B.run("shipped k_avg f2 h1 v1 nt     grid 4x4096", [&](int i) { hipLaunchKernelGGL((k_avg<R_FLOOR, F_ARGB, 2, 1, 1, true>), dim3(4, 4096), dim3(256), 0, 0, aa(i)); }, byavg);
+        B.run("shipped k_avg f2 h2 v2 ycc nt grid 4x4096", [&](int i) { hipLaunchKernelGGL((k_avg<R_FLOOR, F_YCC, 2, 2, 2, true>), dim3(4, 4096), dim3(256), 0, 0, aa(i)); }, byavg);
     }
     return 0;
 }
