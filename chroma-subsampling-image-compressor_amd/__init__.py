@@ -8,7 +8,7 @@ ImageCompressionApp).  There is no CPU compute path in here.
 from . import _native
 from ._native import CsicIOError, CsicRuntimeError, IllegalArgumentException
 from .params import ImageProcessorParams, PixelFormat, ProcessingStep, Rounding, Sampling, make_c_params
-from .compressor import ImageCompressorTop, ImageProcessor, Plan
+from .compressor import FrameGraph, ImageCompressorTop, ImageProcessor, Plan
 from .model import Image, ImageProcessorModel
 from .pipeline import FramePipeline
 from .stages import (ChromaSubsampler, ColorQuantizer, PixelBundle, PixelYCbCrBundle, ReferenceModel, RGB2YCbCr,
@@ -19,7 +19,7 @@ from . import app, compressor, distributed, model, params, pipeline, stages
 
 __all__ = [
     "CsicIOError", "CsicRuntimeError", "IllegalArgumentException", "ImageProcessorParams", "PixelFormat", "ProcessingStep",
-    "Rounding", "Sampling", "make_c_params", "ImageCompressorTop", "ImageProcessor", "Plan", "Image", "ImageProcessorModel",
+    "Rounding", "Sampling", "make_c_params", "ImageCompressorTop", "ImageProcessor", "Plan", "FrameGraph", "Image", "ImageProcessorModel",
     "ImageCompressionApp", "FramePipeline", "ChromaSubsampler", "ColorQuantizer", "PixelBundle", "PixelYCbCrBundle", "ReferenceModel", "RGB2YCbCr",
     "SpatialDownsampler", "YCbCrUtils", "pack_ycc", "unpack_ycc", "Stripe", "StripedImageCompressorTop", "MultiDeviceCompressor", "halo_stripe_for_rank", "stripe_for_rank",
 ]

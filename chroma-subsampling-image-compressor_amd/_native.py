@@ -19,7 +19,8 @@ EIO, EFORMAT = -30, -31
 OP_NOOP, OP_SPATIAL, OP_QUANT, OP_CHROMA = 0, 1, 2, 3
 ROUND_FLOOR_HW, ROUND_TRUNC_SW = 0, 1
 FMT_ARGB8888, FMT_YCBCR888X = 0, 1
-TUNE_VARIANT, TUNE_FORCE_GENERIC, TUNE_NONTEMPORAL, TUNE_NO_VECTOR = 1, 2, 3, 4
+TUNE_VARIANT, TUNE_FORCE_GENERIC, TUNE_NONTEMPORAL, TUNE_NO_VECTOR, TUNE_BLOCK_THREADS = 1, 2, 3, 4, 5
+FRAME_GRAPH_DEFAULT_BRANCHES = 8
 PIPELINE_STAGED, PIPELINE_ZERO_COPY = 0, 1
 
 
@@ -85,6 +86,11 @@ PROTOTYPES = {
     "csic_synth_frame_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]),
     "csic_copy_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "csic_checksum_device": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64), C.c_void_p]),
+    "csic_frame_graph_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
+                                          C.POINTER(C.c_void_p)]),
+    "csic_frame_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "csic_frame_graph_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "csic_frame_graph_destroy": (C.c_int, [C.c_void_p]),
     "csic_png_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "csic_png_read_argb": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t]),
     "csic_png_write_argb": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),

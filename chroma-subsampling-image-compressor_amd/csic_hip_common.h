@@ -1,0 +1,66 @@
+// csic_hip_common.h -- shared by the HIP translation units (csic_kernels.hip, csic_pipeline.hip,
+// csic_multi.hip, csic_graph.hip): error macro, the HIP instantiation of the device guard and the launch
+// descriptor that csic_kernels.hip prepares for the other units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "csic_device_guard.h"
+#include "csic_internal.h"
+
+namespace csic {
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return ::csic::set_error(CSIC_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+struct HipDeviceApi {
+    static int get(int *d) { return (int)hipGetDevice(d); }
+    static int set(int d) { return (int)hipSetDevice(d); }
+};
+using DeviceGuard = BasicDeviceGuard<HipDeviceApi>;
+
+// `CSIC_DEVICE_SCOPE(dev);` at the top of an entry point: `dev` is current until the scope ends, then the
+// caller's device is current again.  Returns CSIC_EHIP from the enclosing function if the switch fails.
+#define CSIC_DEVICE_SCOPE(dev)                                                                              \
+    ::csic::DeviceGuard csic_device_guard_(dev);                                                            \
+    if (csic_device_guard_.status() != 0)                                                                   \
+        return ::csic::set_error(CSIC_EHIP, "cannot make device %d current: %s", (int)(dev),                \
+                                 hipGetErrorString((hipError_t)csic_device_guard_.status()))
+
+// ---- kernel arguments (kernarg segment -> SGPRs) ----------------------------------------------------
+struct KArgs {
+    const uint32_t *in;
+    uint32_t *out;
+    int32_t W, H, Wo, Ho;
+    int32_t last_sample_col;
+    uint32_t my, mcb, mcr;
+    int32_t f, hmask, vmask, s_first;   // hmask = h-1, vmask = v-1 (generic kernel; vmask also k_dec SROWS)
+    int32_t sc_shift, bc_row_off, bc_col_in;   // k_dec SROWS: log2 f; held-sample decimated row offset / input column
+    int64_t in_frame_px, out_frame_px;  // batch strides (grid z = frame)
+    int32_t bdx, bdy, row_step;         // block width/height and gridDim.y * bdy, passed explicitly (see pin_args)
+    int32_t ip, op;                     // row pitch of the input / output frame in pixels (>= W / Wo; == when packed)
+    uint32_t mW, mWo, kW, kWo;          // k_generic: exact n / W and n / Wo for n < 2^31 as (n * m) >> k (see magic_div)
+};
+
+using KernelFn = void (*)(KArgs);
+
+// One fully resolved launch of the fused kernel: what hipLaunchKernel / hipGraphAddKernelNode need.
+struct LaunchDesc {
+    KernelFn fn;
+    dim3 grid, block;
+    KArgs args;
+};
+
+// csic_kernels.hip: validates the call, resolves kernel + geometry for frames [0, nframes) (nframes <= 65535,
+// the grid z limit) and fills *d.  Does not touch the device.
+int prepare_launch(const csic_plan *pl, const void *d_in, void *d_out, int nframes, int32_t in_pitch, int32_t out_pitch,
+                   LaunchDesc *d);
+int enqueue(const LaunchDesc &d, hipStream_t stream);
+int launch_on_stream(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream);
+int plan_device(const csic_plan *pl);
+void plan_sizes(const csic_plan *pl, size_t *in_px, size_t *out_px);
+
+} // namespace csic

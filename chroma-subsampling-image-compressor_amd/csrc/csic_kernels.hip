@@ -31,31 +31,15 @@
 //              reference semantics, never the default; see the section comment further down.
 //
 // Citations are relative to /root/reference/.
-#include <hip/hip_runtime.h>
-
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <tuple>
+#include <utility>
 
-#include "csic_internal.h"
+#include "csic_hip_common.h"
 
 namespace csic {
-
-// ------------------------------------------------------------------------------------------------
-// kernel arguments (kernarg segment -> SGPRs)
-// ------------------------------------------------------------------------------------------------
-struct KArgs {
-    const uint32_t *in;
-    uint32_t *out;
-    int32_t W, H, Wo, Ho;
-    int32_t last_sample_col;
-    uint32_t my, mcb, mcr;
-    int32_t f, hmask, vmask, s_first;   // hmask = h-1, vmask = v-1 (generic kernel; vmask also k_dec SROWS)
-    int32_t sc_shift, bc_row_off, bc_col_in;   // k_dec SROWS: log2 f; held-sample decimated row offset / input column
-    int64_t in_frame_px, out_frame_px;  // batch strides (grid z = frame)
-    int32_t bdx, bdy, row_step;         // block width/height and gridDim.y * bdy, passed explicitly (see pin_args)
-    int32_t ip, op;                     // row pitch of the input / output frame in pixels (>= W / Wo; == when packed)
-};
 
 // Wave prologue.  hipcc sinks every kernel-argument s_load to its first use, and blockDim/gridDim come
 // from the hidden-argument area, so a kernel with early exits pays 3-4 DEPENDENT scalar-load round
@@ -560,10 +544,11 @@ __global__ void __launch_bounds__(256) k_generic(KArgs a)
         } else {
             // chroma sits behind the decimator but was built with the full width
             // (ImageCompressorTop.scala:52-58): its column counter wraps every W decimated pixels.
+            // The two divisions by run-time constants are exact multiply-shifts (magic_div, host side).
             const int j = ro * a.Wo + co;               // < 2^31 (validated)
-            const int r = j / a.W, c = j - r * a.W;
+            const int r = (int)(((uint64_t)(uint32_t)j * a.mW) >> a.kW), c = j - r * a.W;
             const int src = ((r & a.vmask) == 0) ? (j - (c & a.hmask)) : ((r - 1) * a.W + a.last_sample_col);
-            const int sro = src / a.Wo, sco = src - sro * a.Wo;
+            const int sro = (int)(((uint64_t)(uint32_t)src * a.mWo) >> a.kWo), sco = src - sro * a.Wo;
             c_idx = (int64_t)(sro * a.f) * a.ip + sco * a.f;       // (counters above use the semantic W, addresses the pitch)
         }
         uint32_t cb, cr;
@@ -610,8 +595,6 @@ __global__ void __launch_bounds__(256) k_checksum(const uint32_t *src, int64_t n
 // ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
-using KernelFn = void (*)(KArgs);
-
 enum Family { FAM_F1X4, FAM_DEC, FAM_DEC2V1, FAM_DEC2V2, FAM_GENERIC, FAM_AVG, FAM_AVG_GENERIC };
 
 } // namespace csic
@@ -625,6 +608,7 @@ struct csic_plan {
     int no_vec;          // 1 = no 16-byte vector kernels (set per launch for pointers that are only 4-byte aligned)
     int dec_hold;        // k_dec: lane-hold distance of the selected kernel (1, 2 or 4)
     int no_nt;           // 1 = plain (cached) loads/stores instead of non-temporal ones
+    int block_threads;   // 0 = default (256); 64 / 128 = smaller blocks (CSIC_TUNE_BLOCK_THREADS)
     // selection (recomputed by select())
     csic::Family fam;
     csic::KernelFn fn;
@@ -637,13 +621,6 @@ struct csic_plan {
 };
 
 namespace csic {
-
-#define HIP_TRY(expr)                                                                            \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return set_error(CSIC_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));          \
-    } while (0)
 
 template <int ROUND, int FMT, bool NT>
 static KernelFn pick_f1x4(int h, int v)
@@ -797,22 +774,24 @@ static void select(csic_plan *pl)
 
 static int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-static int ensure_device(const csic_plan *pl)
+// Exact unsigned division by a run-time constant without a divide: for 1 <= d < 2^31 and every n < 2^31,
+//   n / d == (uint64(n) * m) >> k   with  k = 31 + ceil(log2 d),  m = ceil(2^k / d)  (m < 2^32).
+// (Error term e = m*d - 2^k < d <= 2^ceil(log2 d), and n * e < 2^31 * 2^ceil(log2 d) = 2^k.)
+static void magic_div(uint32_t d, uint32_t *m, uint32_t *k)
 {
-    int cur = -1;
-    HIP_TRY(hipGetDevice(&cur));
-    if (cur != pl->device) HIP_TRY(hipSetDevice(pl->device));
-    return CSIC_OK;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    *k = 31 + l;
+    *m = (uint32_t)(((1ull << *k) + d - 1) / d);
 }
 
-static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream,
-                  int32_t in_pitch = 0, int32_t out_pitch = 0)
+int prepare_launch(const csic_plan *pl, const void *d_in, void *d_out, int nframes, int32_t in_pitch, int32_t out_pitch,
+                   LaunchDesc *d)
 {
     if (!pl) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
     if (!d_in || !d_out) return set_error(CSIC_EINVAL_NULL, "device buffer is NULL");
-    if (nframes <= 0) return set_error(CSIC_EINVAL_SIZE, "nframes must be positive. Got %d", nframes);
-    int st = ensure_device(pl);
-    if (st != CSIC_OK) return st;
+    if (nframes <= 0 || nframes > 65535)
+        return set_error(CSIC_EINVAL_SIZE, "nframes per launch must be in 1..65535. Got %d", nframes);
     const Geometry &g = pl->g;
 
     Family fam = pl->fam;
@@ -830,7 +809,7 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
         fam = tmp.fam; fn = tmp.fn; units = tmp.units_per_row; kpl = tmp.k_per_lane; dec_hold = tmp.dec_hold;
     }
 
-    KArgs a;
+    KArgs &a = d->args;
     a.in = static_cast<const uint32_t *>(d_in);
     a.out = static_cast<uint32_t *>(d_out);
     a.W = g.W; a.H = g.H; a.Wo = g.Wo; a.Ho = g.Ho;
@@ -843,11 +822,15 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
     a.sc_shift = (g.f == 8) ? 3 : (g.f == 4) ? 2 : (g.f == 2) ? 1 : 0;
     a.bc_row_off = g.last_sample_col / g.Wo;             // only meaningful (and only used) when f | W
     a.bc_col_in = (g.last_sample_col % g.Wo) * g.f;
+    magic_div((uint32_t)g.W, &a.mW, &a.kW);
+    magic_div((uint32_t)g.Wo, &a.mWo, &a.kWo);
 
+    // threads per block: 256 by default; CSIC_TUNE_BLOCK_THREADS (64 / 128 / 256) for A/B on small launches
+    const int tpb = (pl->block_threads == 64 || pl->block_threads == 128) ? pl->block_threads : 256;
     const int rows = (fam == FAM_F1X4) ? g.H : (fam == FAM_AVG) ? g.H / (g.f > g.v ? g.f : g.v) : g.Ho;
     const int lanes_x = (units + kpl - 1) / kpl;
     int bx = pow2_ceil(lanes_x);
-    if (bx > 256) bx = 256;
+    if (bx > tpb) bx = tpb;
     if (bx < 1) bx = 1;
     if (fam == FAM_DEC && units % kpl == 0) {
         // Rows that do not tile into power-of-two chunks (1920/3840-wide video: Wo = 960, 1920, ...) would put
@@ -855,27 +838,61 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
         // every block on the straight-line path (4K f=2: 70 % -> 80 % of HBM peak).  The width only has to
         // be a multiple of the lane-hold distance so that a DPP hold group never straddles two rows.
         const int hold = dec_hold > 0 ? dec_hold : 1;
-        if (lanes_x <= 256) {
+        if (lanes_x <= tpb) {
             if (lanes_x % hold == 0) bx = lanes_x;
         } else {
-            for (int m = (lanes_x + 255) / 256; m <= lanes_x / 128; ++m)
+            for (int m = (lanes_x + tpb - 1) / tpb; m <= lanes_x / (tpb / 2); ++m)
                 if (lanes_x % m == 0 && (lanes_x / m) % hold == 0) { bx = lanes_x / m; break; }
         }
     }
-    const int by = 256 / bx;
-    dim3 block(bx, by, 1);
+    const int by = tpb / bx > 0 ? tpb / bx : 1;
+    d->block = dim3(bx, by, 1);
     unsigned gx = (unsigned)((lanes_x + bx - 1) / bx);
     unsigned gy = (unsigned)((rows + by - 1) / by);
     if (gy > 65535u) gy = 65535u;                     // kernels stride over rows
     a.bdx = bx; a.bdy = by; a.row_step = (int32_t)gy * by;
+    d->grid = dim3(gx, gy, (unsigned)nframes);
+    d->fn = fn;
+    return CSIC_OK;
+}
+
+template <class T, size_t... I>
+static void fill_ptrs(void **p, T &t, std::index_sequence<I...>) { ((p[I] = &std::get<I>(t)), ...); }
+
+template <class... A, class... B>
+static hipError_t launch_k(void (*k)(A...), dim3 grid, dim3 block, hipStream_t stream, B... args)
+{
+    std::tuple<A...> t(static_cast<A>(args)...);
+    void *p[sizeof...(A)];
+    fill_ptrs(p, t, std::index_sequence_for<A...>{});
+    return hipLaunchKernel(reinterpret_cast<const void *>(k), grid, block, p, 0, stream);
+}
+
+// hipLaunchKernel reports this launch's own error: a pending error of the host's earlier, unrelated
+// runtime calls is neither consumed nor mistaken for ours.
+int enqueue(const LaunchDesc &d, hipStream_t stream)
+{
+    KArgs a = d.args;
+    void *params[1] = {&a};
+    HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(d.fn), d.grid, d.block, params, 0, stream));
+    return CSIC_OK;
+}
+
+static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream,
+                  int32_t in_pitch = 0, int32_t out_pitch = 0)
+{
+    if (!pl) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
+    if (nframes <= 0) return set_error(CSIC_EINVAL_SIZE, "nframes must be positive. Got %d", nframes);
+    CSIC_DEVICE_SCOPE(pl->device);
     for (int f0 = 0; f0 < nframes; f0 += 65535) {     // grid z limit
         const int nz = (nframes - f0 < 65535) ? nframes - f0 : 65535;
-        KArgs b = a;
-        b.in += (int64_t)f0 * a.in_frame_px;
-        b.out += (int64_t)f0 * a.out_frame_px;
-        (void)hipGetLastError();                      // drop a stale error of an earlier, unrelated runtime call
-        hipLaunchKernelGGL(fn, dim3(gx, gy, (unsigned)nz), block, 0, stream, b);
-        HIP_TRY(hipGetLastError());
+        LaunchDesc d;
+        int st = prepare_launch(pl, d_in, d_out, nz, in_pitch, out_pitch, &d);
+        if (st != CSIC_OK) return st;
+        d.args.in += (int64_t)f0 * d.args.in_frame_px;
+        d.args.out += (int64_t)f0 * d.args.out_frame_px;
+        st = enqueue(d, stream);
+        if (st != CSIC_OK) return st;
     }
     clear_error();
     return CSIC_OK;
@@ -935,7 +952,8 @@ int csic_plan_destroy(csic_plan *plan)
 {
     if (!plan) return CSIC_OK;
     if (plan->d_in || plan->d_out || plan->d_sum) {
-        if (ensure_device(plan) == CSIC_OK) {
+        DeviceGuard guard(plan->device);
+        if (guard.status() == 0) {
             if (plan->d_in) (void)hipFree(plan->d_in);
             if (plan->d_out) (void)hipFree(plan->d_out);
             if (plan->d_sum) (void)hipFree(plan->d_sum);
@@ -954,6 +972,11 @@ int csic_plan_tune(csic_plan *plan, int32_t knob, int32_t value)
     else if (knob == CSIC_TUNE_FORCE_GENERIC) plan->force_generic = value ? 1 : 0;
     else if (knob == CSIC_TUNE_NONTEMPORAL) plan->no_nt = value ? 0 : 1;
     else if (knob == CSIC_TUNE_NO_VECTOR) plan->no_vec = value ? 1 : 0;
+    else if (knob == CSIC_TUNE_BLOCK_THREADS) {
+        if (value != 0 && value != 64 && value != 128 && value != 256)
+            return set_error(CSIC_EINVAL_SIZE, "block threads must be 0 (default), 64, 128 or 256. Got %d", value);
+        plan->block_threads = value;
+    }
     else return set_error(CSIC_EINVAL_SIZE, "unknown tuning knob %d", knob);
     select(plan);
     clear_error();
@@ -986,8 +1009,8 @@ int csic_process_host(csic_plan *plan, const uint32_t *in, size_t in_px, uint32_
     if (in_px != need_in || out_px != need_out)
         return set_error(CSIC_EINVAL_SIZE, "expected %zu input and %zu output pixels, got %zu and %zu",
                          need_in, need_out, in_px, out_px);
-    int st = ensure_device(plan);
-    if (st != CSIC_OK) return st;
+    CSIC_DEVICE_SCOPE(plan->device);
+    int st;
     if (!plan->d_in) HIP_TRY(hipMalloc(&plan->d_in, need_in * 4));
     if (!plan->d_out) HIP_TRY(hipMalloc(&plan->d_out, need_out * 4));
     HIP_TRY(hipMemcpyAsync(plan->d_in, in, need_in * 4, hipMemcpyHostToDevice, nullptr));
@@ -1006,10 +1029,8 @@ int csic_synth_frame_device(void *d_dst, int64_t npix, int64_t first_index, uint
     if (npix == 0) return CSIC_OK;
     int64_t blocks = (npix + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
-                       static_cast<uint32_t *>(d_dst), npix, first_index, seed * 0x9E3779B9u);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_k(k_synth, dim3((unsigned)blocks), dim3(256), static_cast<hipStream_t>(hip_stream),
+                     static_cast<uint32_t *>(d_dst), npix, first_index, seed * 0x9E3779B9u));
     clear_error();
     return CSIC_OK;
 }
@@ -1022,10 +1043,8 @@ int csic_copy_device(void *d_dst, const void *d_src, int64_t npix, void *hip_str
     if (npix == 0) return CSIC_OK;
     const int64_t n4 = npix / 4, blocks = (n4 + 255) / 256;
     if (blocks > 0x7FFFFFFF) return set_error(CSIC_EINVAL_SIZE, "copy too large for one launch");
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(k_copy, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
-                       static_cast<const uint32_t *>(d_src), static_cast<uint32_t *>(d_dst), n4);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_k(k_copy, dim3((unsigned)blocks), dim3(256), static_cast<hipStream_t>(hip_stream),
+                     static_cast<const uint32_t *>(d_src), static_cast<uint32_t *>(d_dst), n4));
     clear_error();
     return CSIC_OK;
 }
@@ -1040,10 +1059,7 @@ int csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *h
     if (e == hipSuccess && npix > 0) {
         int64_t blocks = (npix + 255) / 256;
         if (blocks > 4096) blocks = 4096;
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(k_checksum, dim3((unsigned)blocks), dim3(256), 0, s,
-                           static_cast<const uint32_t *>(d_src), npix, d_sum);
-        e = hipGetLastError();
+        e = launch_k(k_checksum, dim3((unsigned)blocks), dim3(256), s, static_cast<const uint32_t *>(d_src), npix, d_sum);
     }
     unsigned long long h = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&h, d_sum, sizeof h, hipMemcpyDeviceToHost, s);

@@ -3,16 +3,10 @@
 // (torch.distributed), this is the same partition for hosts that own all GPUs in one process (a JVM, a
 // C++ service).  Stripes come from csic_stripe_rows (aligned, independent images): there is no halo and
 // no peer traffic; every device runs the ordinary fused kernel on its stripe, on its own stream.
-#include <hip/hip_runtime.h>
-
 #include <new>
 #include <vector>
 
-#include "csic_internal.h"
-
-namespace csic {
-int launch_on_stream(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream);
-}
+#include "csic_hip_common.h"
 
 struct csic_multi {
     struct Part {
@@ -29,18 +23,12 @@ struct csic_multi {
 
 using namespace csic;
 
-#define HIP_TRY(expr)                                                                            \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return set_error(CSIC_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));          \
-    } while (0)
-
 static void multi_free(csic_multi *m)
 {
     for (auto &p : m->parts) {
         if (!p.plan && !p.stream && !p.d_in && !p.d_out) continue;      // never created (or an invalid device)
-        if (hipSetDevice(p.device) != hipSuccess) { (void)hipGetLastError(); continue; }
+        DeviceGuard guard(p.device);
+        if (guard.status() != 0) continue;
         if (p.stream) { (void)hipStreamSynchronize(p.stream); (void)hipStreamDestroy(p.stream); }
         if (p.d_in) (void)hipFree(p.d_in);
         if (p.d_out) (void)hipFree(p.d_out);
@@ -73,7 +61,8 @@ int csic_multi_create(const csic_params *p, const int32_t *devices, int32_t ndev
         sp.height = q.nrows;
         st = csic_plan_create(&sp, q.device, &q.plan);
         if (st != CSIC_OK) break;
-        hipError_t e = hipSetDevice(q.device);
+        DeviceGuard guard(q.device);
+        hipError_t e = (hipError_t)guard.status();
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking);
         if (e != hipSuccess) st = set_error(CSIC_EHIP, "stream creation on device %d failed: %s", q.device, hipGetErrorString(e));
     }
@@ -120,7 +109,7 @@ int csic_multi_synchronize(csic_multi *m)
     if (!m) return set_error(CSIC_EINVAL_NULL, "multi is NULL");
     for (auto &q : m->parts) {
         if (!q.stream) continue;
-        HIP_TRY(hipSetDevice(q.device));
+        CSIC_DEVICE_SCOPE(q.device);
         HIP_TRY(hipStreamSynchronize(q.stream));
     }
     clear_error();
@@ -135,7 +124,7 @@ int csic_multi_process_host(csic_multi *m, const uint32_t *in, size_t in_px, uin
                          (size_t)m->W * m->H, (size_t)m->Wo * m->Ho, in_px, out_px);
     for (auto &q : m->parts) {                       // scatter + launch + gather, all asynchronous per device
         if (!q.plan) continue;
-        HIP_TRY(hipSetDevice(q.device));
+        CSIC_DEVICE_SCOPE(q.device);
         const size_t ib = (size_t)q.nrows * m->W * 4, ob = (size_t)q.out_nrows * m->Wo * 4;
         if (!q.d_in) HIP_TRY(hipMalloc(&q.d_in, ib));
         if (!q.d_out) HIP_TRY(hipMalloc(&q.d_out, ob));

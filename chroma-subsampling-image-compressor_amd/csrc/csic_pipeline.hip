@@ -7,18 +7,10 @@
 // input/output buffers and its own HIP stream; a frame's H2D copy, kernel and D2H copy are ordered on its
 // slot's stream, and different slots overlap on the copy engines and the CUs.  The producer writes (or
 // decodes) straight into the pinned input buffer it acquired, so no extra host copy is needed.
-#include <hip/hip_runtime.h>
-
 #include <new>
 #include <vector>
 
-#include "csic_internal.h"
-
-namespace csic {
-int launch_on_stream(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream);  // csic_kernels.hip
-int plan_device(const csic_plan *pl);
-void plan_sizes(const csic_plan *pl, size_t *in_px, size_t *out_px);
-}
+#include "csic_hip_common.h"
 
 struct csic_pipeline {
     struct Slot {
@@ -42,21 +34,6 @@ struct csic_pipeline {
 };
 
 using namespace csic;
-
-#define HIP_TRY(expr)                                                                            \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return set_error(CSIC_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));          \
-    } while (0)
-
-static int set_dev(const csic_pipeline *pp)
-{
-    int cur = -1;
-    HIP_TRY(hipGetDevice(&cur));
-    if (cur != pp->device) HIP_TRY(hipSetDevice(pp->device));
-    return CSIC_OK;
-}
 
 static void free_slots(csic_pipeline *pp)
 {
@@ -84,8 +61,12 @@ int csic_pipeline_create(csic_plan *plan, int32_t depth, csic_pipeline **out)
     pp->plan = plan;
     pp->device = plan_device(plan);
     plan_sizes(plan, &pp->in_px, &pp->out_px);
-    int st = set_dev(pp);
-    if (st != CSIC_OK) { delete pp; return st; }
+    DeviceGuard guard(pp->device);
+    if (guard.status() != 0) {
+        const int dev = pp->device;
+        delete pp;
+        return set_error(CSIC_EHIP, "cannot make device %d current: %s", dev, hipGetErrorString((hipError_t)guard.status()));
+    }
     try { pp->slots.resize(depth); } catch (const std::bad_alloc &) { delete pp; return set_error(CSIC_ENOMEM, "out of host memory"); }
     hipError_t e = hipSuccess;
     for (auto &s : pp->slots) {
@@ -109,7 +90,10 @@ int csic_pipeline_create(csic_plan *plan, int32_t depth, csic_pipeline **out)
 int csic_pipeline_destroy(csic_pipeline *pp)
 {
     if (!pp) return CSIC_OK;
-    if (set_dev(pp) == CSIC_OK) free_slots(pp);
+    {
+        DeviceGuard guard(pp->device);
+        if (guard.status() == 0) free_slots(pp);
+    }
     delete pp;
     return CSIC_OK;
 }
@@ -131,8 +115,8 @@ int csic_pipeline_submit(csic_pipeline *pp, int64_t *ticket)
 {
     if (!pp) return set_error(CSIC_EINVAL_NULL, "pipeline is NULL");
     if (pp->acquired < 0) return set_error(CSIC_EINVAL_SIZE, "no acquired input buffer to submit");
-    int st = set_dev(pp);
-    if (st != CSIC_OK) return st;
+    CSIC_DEVICE_SCOPE(pp->device);
+    int st;
     csic_pipeline::Slot &s = pp->slots[pp->acquired];
     if (pp->mode == CSIC_PIPELINE_ZERO_COPY) {
         // The kernel streams the pinned host frame over PCIe itself and writes the result straight back:
@@ -161,8 +145,7 @@ int csic_pipeline_collect(csic_pipeline *pp, const uint32_t **host_out, int64_t 
 {
     if (!pp || !host_out) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
     if (pp->pending == 0) return set_error(CSIC_EINVAL_SIZE, "no submitted frame to collect");
-    int st = set_dev(pp);
-    if (st != CSIC_OK) return st;
+    CSIC_DEVICE_SCOPE(pp->device);
     csic_pipeline::Slot &s = pp->slots[pp->tail];
     HIP_TRY(hipEventSynchronize(s.done));
     *host_out = s.h_out;

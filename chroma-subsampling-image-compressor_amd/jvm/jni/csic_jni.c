@@ -5,6 +5,14 @@
  *   cc -O2 -fPIC -shared -I"$JAVA_HOME/include" -I"$JAVA_HOME/include/linux" -I../../../include \
  *      jni/csic_jni.c -L.. -lcsic_hip -Wl,-rpath,'$ORIGIN' -o ../libcsic_jni.so
  *
+ * Symbol names.  jpeg.NativeBackend is a Scala `object`: scalac compiles its `@native def`s to INSTANCE methods
+ * of the module class `jpeg.NativeBackend$` (the static forwarders it adds to class `NativeBackend` are plain
+ * bytecode that calls MODULE$.m(), not native methods).  The JVM therefore resolves
+ *     Java_jpeg_NativeBackend_00024_<method>(JNIEnv *, jobject self, ...)
+ * -- `$` is escaped as `_00024` (JNI spec, "Resolving Native Method Names") and the second parameter is the
+ * module instance, not a jclass.  tests/test_jni_symbols.py derives these names from NativeBackend.scala and
+ * checks them against this file, so the two cannot drift apart unnoticed while no JDK is available to link them.
+ *
  * Ownership: no jarray reference is kept past a call; pixel arrays are pinned with
  * GetPrimitiveArrayCritical only for the duration of csic_process_host.
  */
@@ -37,17 +45,17 @@ static void fill(JNIEnv *env, jintArray jp, csic_params *p)
     memcpy(p, v, sizeof *p);
 }
 
-JNIEXPORT void JNICALL Java_jpeg_NativeBackend_validate(JNIEnv *env, jclass c, jintArray jp)
+JNIEXPORT void JNICALL Java_jpeg_NativeBackend_00024_validate(JNIEnv *env, jobject self, jintArray jp)
 {
-    (void)c;
+    (void)self;
     csic_params p; fill(env, jp, &p);
     int st = csic_validate(&p);
     if (st != CSIC_OK) throw_for(env, st);
 }
 
-JNIEXPORT jlong JNICALL Java_jpeg_NativeBackend_planCreate(JNIEnv *env, jclass c, jintArray jp, jint device)
+JNIEXPORT jlong JNICALL Java_jpeg_NativeBackend_00024_planCreate(JNIEnv *env, jobject self, jintArray jp, jint device)
 {
-    (void)c;
+    (void)self;
     csic_params p; fill(env, jp, &p);
     csic_plan *plan = NULL;
     int st = csic_plan_create(&p, device, &plan);
@@ -55,15 +63,15 @@ JNIEXPORT jlong JNICALL Java_jpeg_NativeBackend_planCreate(JNIEnv *env, jclass c
     return (jlong)(intptr_t)plan;
 }
 
-JNIEXPORT void JNICALL Java_jpeg_NativeBackend_planDestroy(JNIEnv *env, jclass c, jlong h)
+JNIEXPORT void JNICALL Java_jpeg_NativeBackend_00024_planDestroy(JNIEnv *env, jobject self, jlong h)
 {
-    (void)env; (void)c;
+    (void)env; (void)self;
     csic_plan_destroy((csic_plan *)(intptr_t)h);
 }
 
-JNIEXPORT jintArray JNICALL Java_jpeg_NativeBackend_outDims(JNIEnv *env, jclass c, jintArray jp)
+JNIEXPORT jintArray JNICALL Java_jpeg_NativeBackend_00024_outDims(JNIEnv *env, jobject self, jintArray jp)
 {
-    (void)c;
+    (void)self;
     csic_params p; fill(env, jp, &p);
     int32_t wh[2];
     int st = csic_out_dims(&p, &wh[0], &wh[1]);
@@ -74,9 +82,9 @@ JNIEXPORT jintArray JNICALL Java_jpeg_NativeBackend_outDims(JNIEnv *env, jclass 
 }
 
 /* in: ARGB ints (Java int == CSIC_FMT_ARGB8888); out: ARGB or Y|Cb<<8|Cr<<16 per the plan's out_format */
-JNIEXPORT void JNICALL Java_jpeg_NativeBackend_process(JNIEnv *env, jclass c, jlong h, jintArray jin, jintArray jout)
+JNIEXPORT void JNICALL Java_jpeg_NativeBackend_00024_process(JNIEnv *env, jobject self, jlong h, jintArray jin, jintArray jout)
 {
-    (void)c;
+    (void)self;
     const jsize nin = (*env)->GetArrayLength(env, jin), nout = (*env)->GetArrayLength(env, jout);
     void *pin = (*env)->GetPrimitiveArrayCritical(env, jin, NULL);
     void *pout = (*env)->GetPrimitiveArrayCritical(env, jout, NULL);

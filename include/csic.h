@@ -174,11 +174,13 @@ const char *csic_plan_kernel_name(const csic_plan *plan);
  *   CSIC_TUNE_VARIANT : kernel-family specific variant index (0 = default)
  *   CSIC_TUNE_FORCE_GENERIC : 1 = always use the one-thread-per-pixel generic kernel
  *   CSIC_TUNE_NONTEMPORAL   : 1 (default) = non-temporal loads/stores for the frame stream, 0 = cached
- *   CSIC_TUNE_NO_VECTOR     : 1 = never use the 16-byte-per-lane kernels */
+ *   CSIC_TUNE_NO_VECTOR     : 1 = never use the 16-byte-per-lane kernels
+ *   CSIC_TUNE_BLOCK_THREADS : threads per block, 64 / 128 / 256 (0 = default 256) */
 #define CSIC_TUNE_VARIANT        1
 #define CSIC_TUNE_FORCE_GENERIC  2
 #define CSIC_TUNE_NONTEMPORAL    3
 #define CSIC_TUNE_NO_VECTOR      4   /* 1 = 4-byte accesses only (what unaligned pointers get automatically) */
+#define CSIC_TUNE_BLOCK_THREADS  5   /* 0 (default) = 256 threads per block; 64 or 128 = smaller blocks      */
 int  csic_plan_tune(csic_plan *plan, int32_t knob, int32_t value);
 
 /* One frame, device-resident: d_in holds width*height input pixels, d_out receives
@@ -220,6 +222,29 @@ int  csic_copy_device(void *d_dst, const void *d_src, int64_t npix, void *hip_st
 /* 64-bit order-sensitive checksum of npix pixels in device memory (sum of fmix32-mixed
  * (pixel, index) pairs), for the full-size parity properties; synchronous. */
 int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *hip_stream);
+
+/* ---- per-frame launches captured in one hipGraph (BASELINE.json configs[4], "hipGraph-captured per-frame
+ * launch") ---------------------------------------------------------------------------------------------
+ * A stream of frames that live in SEPARATE device buffers (a decoder's surface pool) cannot use the one
+ * contiguous batched launch of csic_process_batch_device.  csic_frame_graph_create builds a hipGraph with one
+ * kernel node per frame (frame k: d_in[k] -> d_out[k]; same preconditions as csic_process_device) and
+ * instantiates it once; csic_frame_graph_launch replays it on `hip_stream`.  The reference processes images
+ * strictly one after the other (ImageCompressorTopApp.scala:23-145, one DUT per image); frames are independent,
+ * so the only ordering the graph keeps is what `branches` asks for:
+ *   branches = 1 : a chain, frame k+1 after frame k -- what capturing a loop of csic_process_device calls on ONE
+ *                  stream yields; every node pays the dependent-kernel boundary (~1.7 us on MI355X).
+ *   branches = B : B independent chains (frame k depends on frame k-B), so up to B frame kernels are in flight
+ *                  and one frame's launch ramp and drain overlap its neighbours' streaming.
+ *   branches <= 0: the library's default (CSIC_FRAME_GRAPH_DEFAULT_BRANCHES).
+ * All outputs are complete when work enqueued on `hip_stream` after the launch runs.  The pointer arrays are
+ * read at creation only; the buffers they name must stay valid for as long as the graph is launched. */
+#define CSIC_FRAME_GRAPH_DEFAULT_BRANCHES 8
+typedef struct csic_frame_graph csic_frame_graph;
+int  csic_frame_graph_create(csic_plan *plan, const void *const *d_in, void *const *d_out, int32_t nframes,
+                             int32_t branches, csic_frame_graph **out);
+int  csic_frame_graph_launch(csic_frame_graph *graph, void *hip_stream);
+int  csic_frame_graph_count(const csic_frame_graph *graph, int32_t *nframes, int32_t *branches);
+int  csic_frame_graph_destroy(csic_frame_graph *graph);
 
 /* ---- PNG files (host only, zlib) --------------------------------------------------------------------
  * The codec either side of the path: stands in for scrimage's loader / PngWriter behind

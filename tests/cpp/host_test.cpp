@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "csic.hpp"
+#include "../../chroma-subsampling-image-compressor_amd/csrc/csic_device_guard.h"
 
 using namespace csic;
 using PS = ProcessingStep;
@@ -33,6 +34,34 @@ static void cpu_checks()
     try { ImageProcessorParams(16, 16, 3, 4, 4); } catch (const IllegalArgumentException &e) {
         EXPECT(std::strstr(e.what(), "requirement failed: factor must be 1, 2, 4, or 8") != nullptr);
     }
+}
+
+// The device guard every csic_* entry point opens (csrc/csic_device_guard.h), driven by a fake runtime: it must
+// switch only when needed, always put the caller's device back, and surface get/set failures without switching.
+struct FakeRt {
+    static int cur, sets, fail_get, fail_set_on;
+    static int get(int *d) { if (fail_get) return 101; *d = cur; return 0; }
+    static int set(int d) { if (d == fail_set_on) return 100; cur = d; ++sets; return 0; }
+};
+int FakeRt::cur = 0, FakeRt::sets = 0, FakeRt::fail_get = 0, FakeRt::fail_set_on = -1;
+
+static void device_guard_checks()
+{
+    using Guard = BasicDeviceGuard<FakeRt>;
+    FakeRt::cur = 3; FakeRt::sets = 0;
+    { Guard g(3); EXPECT(g.status() == 0 && !g.switched() && FakeRt::cur == 3); }
+    EXPECT(FakeRt::cur == 3 && FakeRt::sets == 0);                 // same device: no runtime call at all
+    { Guard g(5); EXPECT(g.status() == 0 && g.switched() && g.previous() == 3 && FakeRt::cur == 5); }
+    EXPECT(FakeRt::cur == 3 && FakeRt::sets == 2);                 // switched and restored
+    { Guard outer(1); { Guard inner(2); EXPECT(FakeRt::cur == 2); } EXPECT(FakeRt::cur == 1); }
+    EXPECT(FakeRt::cur == 3);                                      // nesting unwinds in order
+    FakeRt::fail_set_on = 7;
+    { Guard g(7); EXPECT(g.status() == 100 && !g.switched() && FakeRt::cur == 3); }
+    EXPECT(FakeRt::cur == 3);                                      // failed switch: nothing to restore
+    FakeRt::fail_set_on = -1; FakeRt::fail_get = 1;
+    { Guard g(4); EXPECT(g.status() == 101 && !g.switched()); }
+    FakeRt::fail_get = 0;
+    EXPECT(FakeRt::cur == 3);
 }
 
 static uint32_t argb(int r, int g, int b) { return 0xFF000000u | (r << 16) | (g << 8) | b; }
@@ -114,6 +143,7 @@ static void png_checks(const char *in_png)
 int main(int argc, char **argv)
 {
     cpu_checks();
+    device_guard_checks();
     if (argc > 2) png_checks(argv[2]);
     if (argc > 1 && std::strcmp(argv[1], "gpu") == 0) {
         gpu_checks();

@@ -1,0 +1,137 @@
+"""csic_frame_graph_* (BASELINE.json configs[4]: "hipGraph-captured per-frame launch") against the oracle.
+
+The literal cfg 5 workload -- 64 x (3840x2160), 4:2:0, sf=4, Y3Cb3Cr2, chroma->spatial->quant -- is run three
+ways (serial graph, forked graph, one batched launch) and every one of the 64 output frames is compared,
+bit for bit, with the oracle's closed form.  Run with `-m gpu` on an MI355X."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CSQ = (3, 1, 2)
+
+
+@pytest.fixture(scope="module")
+def csic():
+    import csic_amd
+    assert csic_amd._native.lib().csic_device_count() >= 1
+    return csic_amd
+
+
+def _oparams(orc, W, H, a, b, bits, f, op=CSQ, rounding=0):
+    return orc.OracleParams(width=W, height=H, chroma_a=a, chroma_b=b, y_bits=bits[0], cb_bits=bits[1],
+                            cr_bits=bits[2], factor=f, op=op, rounding=rounding)
+
+
+@pytest.mark.parametrize("branches", [1, 2, 3, None, 64])
+def test_frame_graph_small_frames(csic, oracle, branches):
+    """7 frames in SEPARATE allocations (not one contiguous batch), every chain layout."""
+    import torch
+    W, H, n = 200, 36, 7
+    cp = csic.make_c_params(W, H, 2, 0, 3, 3, 2, 2, CSQ)
+    host = [oracle.synth_frame(W * H, 1000 * k) for k in range(n)]
+    with csic.Plan(cp, 0) as pl:
+        d_ins = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
+        d_outs = [torch.zeros(pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+        with csic.FrameGraph(pl, d_ins, d_outs, branches=branches) as g:
+            assert g.nframes == n and 1 <= g.branches <= n
+            for rep in range(3):                                       # a graph is replayable
+                for t in d_outs:
+                    t.zero_()
+                g.launch()
+                torch.cuda.synchronize()
+                for k in range(n):
+                    want = oracle.process(_oparams(oracle, W, H, 2, 0, (3, 3, 2), 2), host[k], form="closed")
+                    assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(want.shape), want), (rep, k)
+
+
+def test_frame_graph_every_kernel_family(csic, oracle):
+    """f = 1 vector kernel, k_dec in both order classes, k_generic and the AVG extension through graph nodes."""
+    import torch
+    n = 3
+    cases = [(64, 24, 2, 2, 1, CSQ, 0), (64, 24, 2, 0, 1, CSQ, 0), (120, 40, 1, 1, 2, CSQ, 0), (128, 64, 2, 0, 4, (1, 2, 3), 0),
+             (50, 30, 2, 0, 4, (1, 3, 2), 0), (96, 32, 2, 0, 2, CSQ, 1)]
+    for (W, H, a, b, f, op, sampling) in cases:
+        cp = csic.make_c_params(W, H, a, b, 5, 4, 3, f, op, sampling=sampling)
+        host = [oracle.synth_frame(W * H, 31 * k + W) for k in range(n)]
+        with csic.Plan(cp, 0) as pl:
+            d_ins = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
+            d_outs = [torch.zeros(pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+            with csic.FrameGraph(pl, d_ins, d_outs, branches=2) as g:
+                g.launch()
+                torch.cuda.synchronize()
+            for k in range(n):
+                want = oracle.process(_oparams(oracle, W, H, a, b, (5, 4, 3), f, op), host[k],
+                                      form="avg" if sampling else "stream")
+                assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(want.shape), want), (pl.kernel_name, k)
+
+
+def test_frame_graph_errors(csic):
+    import torch
+    N = csic._native
+    cp = csic.make_c_params(64, 16, 4, 4, 8, 8, 8, 1, CSQ)
+    with csic.Plan(cp, 0) as pl:
+        good_in = torch.zeros(64 * 16, dtype=torch.int32, device="cuda:0")
+        good_out = torch.zeros(64 * 16, dtype=torch.int32, device="cuda:0")
+        with pytest.raises(csic.IllegalArgumentException):
+            csic.FrameGraph(pl, [good_in], [good_out[:100]])
+        with pytest.raises(csic.IllegalArgumentException):
+            csic.FrameGraph(pl, [], [])
+        h = C.c_void_p()
+        pin = (C.c_void_p * 1)(C.c_void_p(good_in.data_ptr()))
+        pout = (C.c_void_p * 1)(None)
+        assert N.lib().csic_frame_graph_create(pl._h, pin, pout, 1, 1, C.byref(h)) == N.EINVAL_NULL
+        assert N.lib().csic_frame_graph_create(pl._h, pin, pin, 0, 1, C.byref(h)) == N.EINVAL_SIZE
+        assert N.lib().csic_frame_graph_launch(None, None) == N.EINVAL_NULL
+        assert N.lib().csic_frame_graph_destroy(None) == 0
+
+
+def test_entry_points_leave_the_callers_device_current(csic):
+    """a csic_* call on a plan must not change the calling thread's current HIP device.  On a 1-GPU box
+    the observable part is that the device is still 0 and no sticky error is left behind."""
+    import torch
+    cp = csic.make_c_params(64, 16, 4, 4, 8, 8, 8, 1, CSQ)
+    with csic.Plan(cp, 0) as pl:
+        x = torch.zeros(64 * 16, dtype=torch.int32, device="cuda:0")
+        before = torch.cuda.current_device()
+        pl.process_device(x)
+        pl.process_host(np.zeros(64 * 16, dtype=np.uint32))
+        torch.cuda.synchronize()
+        assert torch.cuda.current_device() == before
+
+
+def test_cfg5_literal_64_frames_graph_and_batched(csic, oracle):
+    """BASELINE.json configs[4] at full size: 64 x 3840x2160 ARGB (2.1 GB, generated on the device), 4:2:0, sf=4,
+    bits 3/3/2.  (1) one hipGraph of 64 per-frame launches in a single chain, (2) the same with 8 chains,
+    (3) one batched launch; all 64 x 3 outputs against orc_process_closed_mt on host copies of the frames."""
+    import torch
+    W, H, n = 3840, 2160, 64
+    N = csic._native
+    lib = N.lib()
+    cp = csic.make_c_params(W, H, 2, 0, 3, 3, 2, 4, CSQ)
+    op = _oparams(oracle, W, H, 2, 0, (3, 3, 2), 4)
+    nthreads = max(1, min(32, len(os.sched_getaffinity(0))))
+    with csic.Plan(cp, 0) as pl:
+        ipx, opx = W * H, pl.out_width * pl.out_height
+        d_in = torch.empty(n * ipx, dtype=torch.int32, device="cuda:0")
+        sh = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        N.check(lib.csic_synth_frame_device(C.c_void_p(d_in.data_ptr()), d_in.numel(), 0, 20250629, sh))
+        outs = {name: torch.zeros(n * opx, dtype=torch.int32, device="cuda:0") for name in ("chain", "forked", "batched")}
+        frames_in = [d_in[k * ipx:(k + 1) * ipx] for k in range(n)]
+        for name, br in (("chain", 1), ("forked", 8)):
+            with csic.FrameGraph(pl, frames_in, [outs[name][k * opx:(k + 1) * opx] for k in range(n)], branches=br) as g:
+                assert (g.nframes, g.branches) == (n, br)
+                g.launch()
+                torch.cuda.synchronize()
+        pl.process_device(d_in, outs["batched"], nframes=n)
+        torch.cuda.synchronize()
+        got = {name: t.cpu().numpy().view(np.uint32).reshape(n, opx) for name, t in outs.items()}
+        for k in range(n):
+            host_frame = frames_in[k].cpu().numpy().view(np.uint32)
+            assert np.array_equal(host_frame, oracle.synth_frame(ipx, k * ipx))      # device generator == oracle's
+            want = oracle.process_mt(op, host_frame, nthreads).reshape(-1)
+            for name in got:
+                assert np.array_equal(got[name][k], want), (name, k)
