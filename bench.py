@@ -4,16 +4,19 @@
 Metric (BASELINE.json): input Mpixels/s end to end (RGB -> YCbCr -> 4:2:0 -> reconstruct), device
 resident packed ARGB in HBM -> reconstructed packed ARGB in HBM, plus the fraction of the HBM roofline.
 
-Workload at N=1: BASELINE.json configs[3] ("cfg 4" of SURVEY.md 8): synthetic 8192x8192 RGB, 4:2:0,
-sf=2, no quantisation, order chroma->spatial->quant.  One "step" = one frame = one kernel launch.
-At N>1 (one process per GPU, launched by torch.distributed.run) the frame is row-striped: the global
-frame is 8192 wide and 8192*N tall, every rank owns one aligned 8192x8192 stripe (weak scaling; the
-stripes are independent images -- csic_stripe_rows -- so there is NO data-path collective; RCCL is
-used only for the barrier and the max-over-ranks of the elapsed time).  `--scaling strong` splits one
-8192x8192 frame N ways instead.
+Workload: BASELINE.json configs[3] ("cfg 4" of SURVEY.md 8): ONE synthetic 8192x8192 RGB frame per step,
+4:2:0, sf=2, no quantisation, order chroma->spatial->quant.
+  N = 1 : one step = one frame = one kernel launch.
+  N > 1 : (one process per GPU, launched by torch.distributed.run) the SAME 8192x8192 frame is row-striped
+          over the N ranks -- STRONG scaling, what configs[3] and the north star name ("Images shard by
+          row-stripe across the 8 GPUs"): rank r owns the aligned stripe csic_stripe_rows gives it
+          (8192 x 8192/N), stripes are independent images, so there is NO data-path collective; RCCL carries
+          only the barrier, the max-over-ranks of the elapsed time and the pixel-count sum.  `value` is that
+          strong split.  The weak-scaling number (global frame 8192 x 8192*N, one full 8192x8192 stripe per
+          rank) is measured afterwards in the same process and reported beside it as "weak": {...}.
 
-Frames rotate through a ring of distinct device buffers (32 frames = 8 GiB of input by default) far
-larger than the 256 MiB Infinity Cache, so the kernel streams from HBM, not from L3.
+Frames rotate through a ring of distinct device buffers (8 GiB of input per GPU by default) far larger
+than the 256 MiB Infinity Cache, so the kernel streams from HBM, not from L3.
 
 Prints ONE JSON line on rank 0.
 """
@@ -28,6 +31,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -45,6 +49,7 @@ AVG_CONFIGS = {"avg_8k_420_sf2": "cfg4", "avg_4k_420_sf4": "cfg5"}
 for _k, _v in AVG_CONFIGS.items():
     CONFIGS[_k] = CONFIGS[_v]
 CSQ = (3, 1, 2)
+SCQ = (1, 3, 2)            # spatial before chroma (the reference app's default order class)
 
 
 def cpu_baseline(W, H, a, b, bits, f, budget_s=10.0):
@@ -99,7 +104,283 @@ def cpu_baseline(W, H, a, b, bits, f, budget_s=10.0):
     return res
 
 
-def main():
+def load_traffic(config, kernel_name, world):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, produced by
+    tools/profile.sh + tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, corrected as
+    MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the process they observe, so this is a
+    lookup -- valid only for the exact sources it was measured on: the entry carries a sha256 of every kernel /
+    selection source file (tools/srchash.py) and the kernel the plan selected; if either differs from this
+    checkout, the traffic is reported as null with the reason."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if world != 1:
+        return None, "traffic is profiled at N=1 only"
+    if not os.path.exists(tpath):
+        return None, "profiles/pmc_traffic.json missing"
+    try:
+        from srchash import kernel_source_sha256
+        ent = json.load(open(tpath)).get(config)
+        if not ent:
+            return None, f"no PMC entry for {config} in profiles/pmc_traffic.json"
+        if ent.get("plan_kernel") != kernel_name:
+            return None, f"stale: PMC entry is for kernel {ent.get('plan_kernel')}, the plan selects {kernel_name}"
+        have = kernel_source_sha256(ROOT)
+        if ent.get("source_sha256") != have:
+            return None, (f"stale: PMC entry measured on sources {str(ent.get('source_sha256'))[:12]}..., this checkout is "
+                          f"{have[:12]}... (re-run tools/profile.sh + tools/pmc_traffic.py)")
+        return ent["hbm_bytes_per_launch"], f"profiles/pmc_traffic.json ({ent['tag']}, sources {have[:12]}): " + ent["note"]
+    except Exception as exc:                                    # a broken artefact must not break the bench
+        return None, f"profiles/pmc_traffic.json unreadable: {exc}"
+
+
+class Workload:
+    """One rank's share of one scaling mode: its stripe, plan, ring of device frames and the step function."""
+
+    def __init__(self, args, csic, torch, dev, dev_index, world, rank, scaling):
+        N = csic._native
+        lib = N.lib()
+        self.N, self.lib, self.torch, self.dev, self.args = N, lib, torch, dev, args
+        W, H, a, b, bits, f, fps = CONFIGS[args.config]
+        if args.frames_per_step > 0:
+            fps = args.frames_per_step
+        self.W, self.H, self.fps, self.scaling = W, H, fps, scaling
+        gH = H * world if scaling == "weak" else H
+        self.global_rows = gH
+        sampling = csic.Sampling.AVG if args.config in AVG_CONFIGS else csic.Sampling.HOLD_DECIMATE
+        order = SCQ if args.order == "scq" else CSQ
+        gparams = csic.make_c_params(W, gH, a, b, *bits, f, order, sampling=sampling)
+        r0, nr, o0, on = (C.c_int32() for _ in range(4))
+        N.check(lib.csic_stripe_rows(C.byref(gparams), world, rank, C.byref(r0), C.byref(nr), C.byref(o0), C.byref(on)))
+        self.row0, self.stripe_rows = r0.value, nr.value
+        if self.stripe_rows == 0:
+            raise SystemExit(f"rank {rank}: empty stripe ({gH} rows over {world} ranks)")
+        self.plan = csic.Plan(csic.make_c_params(W, self.stripe_rows, a, b, *bits, f, order, sampling=sampling), dev_index)
+        if args.variant >= 0:
+            self.plan.tune(N.TUNE_VARIANT, args.variant)
+        if args.no_vector:
+            self.plan.tune(N.TUNE_NO_VECTOR, 1)
+        if args.block_threads:
+            self.plan.tune(N.TUNE_BLOCK_THREADS, args.block_threads)
+        self.in_px, self.out_px = W * self.stripe_rows, self.plan.out_width * self.plan.out_height
+        self.per_frame_graph = bool(args.per_frame_graph and fps > 1)
+        self.lpf = 1 if self.per_frame_graph else fps                     # frames per LAUNCH
+        self.launches_per_step = fps if self.per_frame_graph else 1
+        self.alg_bytes = self.plan.algorithmic_bytes * self.lpf            # per launch
+
+        # ---- ring of distinct frames, generated on the device -----------------------------------
+        step_in_bytes = self.in_px * 4 * fps
+        self.nring = max(2, min(64, (args.ring_mib << 20) // max(step_in_bytes, 1)))
+        self.stream = torch.cuda.current_stream(dev)
+        self.sh = C.c_void_p(self.stream.cuda_stream)
+        self.ins = [torch.empty(self.in_px * fps, dtype=torch.int32, device=dev) for _ in range(self.nring)]
+        self.outs = [torch.empty(self.out_px * fps, dtype=torch.int32, device=dev) for _ in range(self.nring)]
+        for k, t in enumerate(self.ins):
+            first = (k * world + rank) * self.in_px * fps + self.row0 * W
+            N.check(lib.csic_synth_frame_device(C.c_void_p(t.data_ptr()), t.numel(), first, 20250629, self.sh))
+        self.in_ptrs = [C.c_void_p(t.data_ptr()) for t in self.ins]
+        self.out_ptrs = [C.c_void_p(t.data_ptr()) for t in self.outs]
+        self.graphs = []
+        self.step_graph = None
+        self.direct = None
+        self.world = world
+        self._build_step()
+
+    # -- how one step is issued -------------------------------------------------------------------
+    def _build_step(self):
+        args, lib, ph, nring, sh = self.args, self.lib, self.plan._h, self.nring, self.sh
+        in_ptrs, out_ptrs, fps = self.in_ptrs, self.out_ptrs, self.fps
+        import csic_amd as csic
+        if self.per_frame_graph:
+            # BASELINE.json configs[4] literally: a hipGraph of per-frame launches, one graph per ring slot
+            # (csic_frame_graph_*: one kernel node per frame, `--graph-branches` independent chains)
+            for k in range(nring):
+                fin = [self.ins[k][j * self.in_px:(j + 1) * self.in_px] for j in range(fps)]
+                fout = [self.outs[k][j * self.out_px:(j + 1) * self.out_px] for j in range(fps)]
+                self.graphs.append(csic.FrameGraph(self.plan, fin, fout, branches=args.graph_branches or None))
+            self.launch_desc = (f"{fps} per-frame launches per step replayed from a frame graph, CSIC_FRAME_GRAPH_HIP: "
+                                f"{self.graphs[0].branches} hipGraph chain(s) ordered with the launch stream")
+
+            def step(i):
+                self.graphs[i % nring].launch(self.stream)
+                return 0
+        elif fps == 1:
+            self.launch_desc = "one launch per step (csic_process_device), eager, one stream"
+
+            def step(i):
+                return lib.csic_process_device(ph, in_ptrs[i % nring], out_ptrs[i % nring], sh)
+        else:
+            self.launch_desc = f"one batched launch of {fps} frames per step (csic_process_batch_device), eager, one stream"
+
+            def step(i):
+                return lib.csic_process_batch_device(ph, in_ptrs[i % nring], out_ptrs[i % nring], fps, sh)
+        self.step = step
+        # N > 1: the steps are issued from a pre-built frame graph over the ring (CSIC_FRAME_GRAPH_HIP: the SAME
+        # launches, one kernel node per step, in the library's default number of chains for this stripe size --
+        # chain 0 on the launch stream, the others on internal streams, all ordered with the launch stream).  A
+        # strong-scaling stripe at N = 8 is a 3 us launch: a Python loop cannot enqueue those fast enough, and
+        # independent steps that overlap hide each other's launch boundary (profiles/r02_small_launch.md).
+        # N = 1 keeps plain eager launches on one stream (the roofline contract: HIP events around serial launches).
+        use = args.step_graph == "on" or (args.step_graph == "auto" and self.world > 1)
+        if use and not self.per_frame_graph and fps == 1 and args.streams <= 1:
+            self.step_graph = csic.FrameGraph(self.plan, self.ins, self.outs, branches=args.step_chains or None)
+            self.launch_desc = (f"one launch per step; {nring} consecutive steps (the ring) replayed from a frame graph, "
+                                f"CSIC_FRAME_GRAPH_HIP, {self.step_graph.branches} chain(s) ordered with the launch stream")
+
+    # -- the same steps through the direct-dispatch engine (side measurement) ------------------------
+    def build_direct(self, K):
+        """CSIC_FRAME_GRAPH_DIRECT graphs covering exactly K steps: whole-ring graphs plus one for the remainder."""
+        import csic_amd as csic
+        q = self.args.direct_queues or None
+        if self.per_frame_graph:
+            fps = self.fps
+            self.direct = []
+            for k in range(self.nring):
+                fin = [self.ins[k][j * self.in_px:(j + 1) * self.in_px] for j in range(fps)]
+                fout = [self.outs[k][j * self.out_px:(j + 1) * self.out_px] for j in range(fps)]
+                self.direct.append(csic.FrameGraph(self.plan, fin, fout, branches=q, backend="direct"))
+            self.direct_desc = (f"{fps} per-frame launches per step as pre-built AQL packets on {self.direct[0].branches} "
+                                "user-mode queue(s), no barrier bit (CSIC_FRAME_GRAPH_DIRECT)")
+            return
+        main = csic.FrameGraph(self.plan, self.ins, self.outs, branches=q, backend="direct")
+        rem = K % self.nring
+        self.direct = [main, csic.FrameGraph(self.plan, self.ins[:rem], self.outs[:rem], branches=q, backend="direct") if rem else None]
+        self.direct_desc = (f"one launch per step; steps pre-built as AQL packets on {main.branches} user-mode queue(s), "
+                            "no barrier bit (CSIC_FRAME_GRAPH_DIRECT), host wall clock")
+
+    def run_direct(self, K):
+        """Submits exactly K steps and waits for all of them."""
+        if self.per_frame_graph:
+            for i in range(K):
+                self.direct[i % self.nring].submit()
+            for g in self.direct:
+                g.wait()
+            return
+        main, rem = self.direct
+        for _ in range(K // self.nring):
+            main.submit()
+        if rem is not None:
+            rem.submit()
+        main.wait()
+        if rem is not None:
+            rem.wait()
+
+    def run_steps(self, first, count):
+        """Issues steps first .. first+count-1 (asynchronous).  Returns the OR of the launch statuses."""
+        st = 0
+        if self.step_graph is None:
+            step = self.step
+            for i in range(first, first + count):
+                st |= step(i)
+            return st
+        nring, i, end = self.nring, first, first + count
+        while i < end:                                      # whole-ring graph replays, eager launches for the ragged ends
+            if i % nring == 0 and end - i >= nring:
+                self.step_graph.launch(self.stream)
+                i += nring
+            else:
+                st |= self.step(i)
+                i += 1
+        return st
+
+    def close(self):
+        for g in self.graphs:
+            g.close()
+        if self.step_graph is not None:
+            self.step_graph.close()
+        for g in (self.direct or []):
+            if g is not None:
+                g.close()
+        self.plan.close()
+        self.ins = self.outs = None
+        self.torch.cuda.empty_cache()
+
+
+def timed_run(wl, args, torch, dist, world, backend, dev):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides.
+    Returns (elapsed seconds: max over ranks, kernel ms per launch from HIP events on the launch stream)."""
+    N, stream = wl.N, wl.stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    if args.prewarm_ms > 0:                                       # clock conditioning, untimed
+        t_end = time.perf_counter() + args.prewarm_ms * 1e-3
+        i = 0
+        while time.perf_counter() < t_end:
+            wl.run_steps(i, 64)
+            i += 64
+            torch.cuda.synchronize(dev)
+    if wl.run_steps(0, args.warmup) != 0:
+        N.check(wl.step(0))
+    barrier()
+
+    # ---- timed region: exactly K steps ------------------------------------------------------------
+    # ev0/ev1 are HIP events recorded on the launch stream around the K steps: (ev1 - ev0) / launches is the
+    # average launch duration the roofline uses (it includes the ~1-2 us inter-kernel boundary, so it is an
+    # upper bound on the per-kernel time rocprofv3 reports).
+    K = args.steps
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    st = 0
+    if args.streams <= 1 or wl.fps != 1 or wl.per_frame_graph:
+        st = wl.run_steps(0, K)
+    else:                                                         # experiment: round-robin over side streams
+        side = [torch.cuda.Stream(dev) for _ in range(args.streams)]
+        for sd in side:
+            sd.wait_stream(stream)
+        shs = [C.c_void_p(sd.cuda_stream) for sd in side]
+        for i in range(K):
+            st |= wl.lib.csic_process_device(wl.plan._h, wl.in_ptrs[i % wl.nring], wl.out_ptrs[i % wl.nring], shs[i % args.streams])
+        for sd in side:
+            stream.wait_stream(sd)
+    ev1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if st != 0:
+        N.check(wl.step(0))
+        raise SystemExit("a launch failed inside the timed region")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms_avg = ev0.elapsed_time(ev1) / K / wl.launches_per_step
+    return elapsed, kern_ms_avg
+
+
+def timed_direct(wl, args, torch, dist, world, backend, dev):
+    """The same K steps through the direct-dispatch engine (CSIC_FRAME_GRAPH_DIRECT): warm-up, then exactly K steps
+    between barrier + synchronize on both sides, host wall clock, max over ranks.  A side measurement: these
+    launches are not on a HIP stream, so there are no HIP events around them."""
+    K = args.steps
+    wl.build_direct(K)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    torch.cuda.synchronize(dev)
+    if args.prewarm_ms > 0:
+        t_end = time.perf_counter() + args.prewarm_ms * 1e-3
+        while time.perf_counter() < t_end:
+            wl.run_direct(min(K, 4 * wl.nring) if wl.fps == 1 else min(K, 8))
+    wl.run_direct(K)                                              # warm-up: one full pass
+    barrier()
+    t0 = time.perf_counter()
+    wl.run_direct(K)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3000)
@@ -109,9 +390,18 @@ def main():
                          "the GPU reaches its steady-state clocks (a 33 us step does not ramp DPM in 40 launches: "
                          "cfg4 measures 33.9 us/step cold vs 32.5 us/step conditioned)")
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
+    ap.add_argument("--order", default="csq", choices=["csq", "scq"],
+                    help="csq = chroma->spatial->quant (north-star order); scq = spatial->chroma->quant (the reference "
+                         "app's default order class; with f not dividing W it selects k_generic)")
+    ap.add_argument("--frames-per-step", type=int, default=0,
+                    help="override the config's frames per step: N contiguous frames in ONE batched launch "
+                         "(csic_process_batch_device) -- puts the tiny cfg2/cfg3 kernels at a size where the roofline means something")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (CSIC_TUNE_VARIANT); -1 = library default")
     ap.add_argument("--no-vector", action="store_true", help="CSIC_TUNE_NO_VECTOR: 4-byte-access kernels only (A/B)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--block-threads", type=int, default=0, choices=[0, 64, 128, 256], help="CSIC_TUNE_BLOCK_THREADS (A/B)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak", "both"],
+                    help="N>1: strong (default; `value` = ONE frame of the config split N ways, the weak number is measured "
+                         "afterwards and reported beside it), weak (`value` = one full frame per rank), both == strong")
     ap.add_argument("--ring-mib", type=int, default=8192,
                     help="input bytes rotated through (MiB), per GPU.  Measured on cfg4: 2 frames (partly Infinity-"
                          "Cache resident) 31.8 us, 8 frames 32.5 us, 32 and 64 frames 32.65 us -- the default is the "
@@ -122,6 +412,18 @@ def main():
     ap.add_argument("--per-frame-graph", action="store_true",
                     help="multi-frame configs (cfg5): replay a hipGraph of per-frame launches (what BASELINE.json's "
                          "cfg 5 literally names) instead of the single batched launch")
+    ap.add_argument("--graph-branches", type=int, default=0,
+                    help="--per-frame-graph: number of independent chains in the frame graph (0 = library default, "
+                         "1 = strictly serial, what capturing a loop on one stream gives)")
+    ap.add_argument("--step-graph", default="auto", choices=["auto", "on", "off"],
+                    help="issue the (one-launch) steps from a pre-built frame graph over the ring instead of a Python loop "
+                         "(auto: N>1 yes, N=1 no)")
+    ap.add_argument("--step-chains", type=int, default=0,
+                    help="--step-graph: independent hipGraph chains among consecutive steps (0 = library default for the "
+                         "stripe size, 1 = single-stream order)")
+    ap.add_argument("--direct-queues", type=int, default=0,
+                    help="queues of the direct-dispatch side measurement (0 = library default for the frame size)")
+    ap.add_argument("--no-direct", action="store_true", help="skip the direct-dispatch side measurement")
     ap.add_argument("--streams", type=int, default=1,
                     help="EXPERIMENT (default 1 = the contract): issue consecutive steps round-robin on this many HIP "
                          "streams so that one frame's ramp-up overlaps the previous frame's drain.  Per-kernel durations "
@@ -129,14 +431,11 @@ def main():
                          "quantifying headroom only.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
-    import numpy as np
     import torch
     import torch.distributed as dist
     import csic_amd as csic
-    N = csic._native
-    lib = N.lib()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -151,194 +450,135 @@ def main():
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    formed = 1
     if world > 1:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)        # RCCL; barrier + max-reduce only
+            dist.init_process_group("nccl", device_id=dev)        # RCCL; barrier + max/sum reductions only
         else:
             dist.init_process_group("gloo")
+        formed = dist.get_world_size()
+        if formed != world:
+            raise SystemExit(f"process group formed with {formed} ranks, expected {world}")
 
-    W, H, a, b, bits, f, fps = CONFIGS[args.config]
-    # ---- this rank's stripe ---------------------------------------------------------------------
-    gH = H * world if args.scaling == "weak" else H
-    sampling = csic.Sampling.AVG if args.config in AVG_CONFIGS else csic.Sampling.HOLD_DECIMATE
-    gparams = csic.make_c_params(W, gH, a, b, *bits, f, CSQ, sampling=sampling)
-    r0, nr, o0, on = (C.c_int32() for _ in range(4))
-    N.check(lib.csic_stripe_rows(C.byref(gparams), world, rank, C.byref(r0), C.byref(nr), C.byref(o0), C.byref(on)))
-    sH = nr.value
-    plan = csic.Plan(csic.make_c_params(W, sH, a, b, *bits, f, CSQ, sampling=sampling), dev_index)
-    if args.variant >= 0:
-        plan.tune(N.TUNE_VARIANT, args.variant)
-    if args.no_vector:
-        plan.tune(N.TUNE_NO_VECTOR, 1)
-    in_px, out_px = W * sH, plan.out_width * plan.out_height
-    lpf = 1 if args.per_frame_graph else fps                      # frames per launch
-    alg_bytes = plan.algorithmic_bytes * lpf                      # per launch
+    def allsum(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
 
-    # ---- ring of distinct frames, generated on the device ---------------------------------------
-    step_in_bytes = in_px * 4 * fps
-    nring = max(2, min(64, (args.ring_mib << 20) // max(step_in_bytes, 1)))
-    stream = torch.cuda.current_stream(dev)
-    sh = C.c_void_p(stream.cuda_stream)
-    ins = [torch.empty(in_px * fps, dtype=torch.int32, device=dev) for _ in range(nring)]
-    outs = [torch.empty(out_px * fps, dtype=torch.int32, device=dev) for _ in range(nring)]
-    for k, t in enumerate(ins):
-        first = (k * world + rank) * in_px * fps + r0.value * W
-        N.check(lib.csic_synth_frame_device(C.c_void_p(t.data_ptr()), t.numel(), first, 20250629, sh))
-    in_ptrs = [C.c_void_p(t.data_ptr()) for t in ins]
-    out_ptrs = [C.c_void_p(t.data_ptr()) for t in outs]
-    ph = plan._h
-    launches_per_step = 1
-    if fps == 1:
-        def step(i):
-            return lib.csic_process_device(ph, in_ptrs[i % nring], out_ptrs[i % nring], sh)
-    elif not args.per_frame_graph:
-        def step(i):
-            return lib.csic_process_batch_device(ph, in_ptrs[i % nring], out_ptrs[i % nring], fps, sh)
-    else:
-        # one captured graph per ring slot: fps per-frame launches of csic_process_device
-        launches_per_step = fps
-        graphs = []
-        cap = torch.cuda.Stream(dev)
-        cap.wait_stream(stream)
-        with torch.cuda.stream(cap):
-            csh = C.c_void_p(cap.cuda_stream)
-            N.check(lib.csic_process_device(ph, in_ptrs[0], out_ptrs[0], csh))   # warm-up outside capture
-        stream.wait_stream(cap)
-        for k in range(nring):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                gsh = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-                for j in range(fps):
-                    N.check(lib.csic_process_device(ph, C.c_void_p(ins[k].data_ptr() + 4 * j * in_px),
-                                                    C.c_void_p(outs[k].data_ptr() + 4 * j * out_px), gsh))
-            graphs.append(g)
-
-        def step(i):
-            graphs[i % nring].replay()
-            return 0
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    if args.prewarm_ms > 0:                                       # clock conditioning, untimed
-        t_end = time.perf_counter() + args.prewarm_ms * 1e-3
-        i = 0
-        while time.perf_counter() < t_end:
-            for _ in range(64):
-                step(i)
-                i += 1
-            torch.cuda.synchronize(dev)
-    for i in range(args.warmup):
-        N.check(step(i))
-    barrier()
-
-    # ---- timed region: exactly K steps, back to back on one stream ------------------------------
-    # ev0/ev1 are HIP events recorded on the launch stream around the K launches: (ev1 - ev0) / K is
-    # the average launch duration the roofline uses (it includes the ~1-2 us inter-kernel boundary,
-    # so it is an upper bound on the per-kernel time rocprofv3 reports).
+    W, H, a, b, bits, f, _ = CONFIGS[args.config]
     K = args.steps
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    st = 0
-    if args.streams <= 1 or fps != 1 or args.per_frame_graph:
-        for i in range(K):
-            st |= step(i)
-    else:                                                         # experiment: round-robin over side streams
-        side = [torch.cuda.Stream(dev) for _ in range(args.streams)]
-        for sd in side:
-            sd.wait_stream(stream)
-        shs = [C.c_void_p(sd.cuda_stream) for sd in side]
-        for i in range(K):
-            st |= lib.csic_process_device(ph, in_ptrs[i % nring], out_ptrs[i % nring], shs[i % args.streams])
-        for sd in side:
-            stream.wait_stream(sd)
-    ev1.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if st != 0:
-        N.check(step(0))
-        raise SystemExit("a launch failed inside the timed region")
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms_avg = ev0.elapsed_time(ev1) / K / launches_per_step
+    headline_mode = "weak" if args.scaling == "weak" else "strong"
 
-    # ---- diagnostic (untimed): an event pair around each of a few launches ----------------------
+    # ---- headline run --------------------------------------------------------------------------------
+    wl = Workload(args, csic, torch, dev, dev_index, world, rank, headline_mode)
+    elapsed, kern_ms_avg = timed_run(wl, args, torch, dist, world, args.backend, dev)
+    total_px = allsum(float(wl.in_px) * wl.fps * K)                # real per-rank pixel counts, summed
+    value = total_px / elapsed / 1e6
+    achieved = wl.alg_bytes / (kern_ms_avg * 1e-3) / 1e9
+    stream = wl.stream
+
+    # ---- diagnostic (untimed): an event pair around each of a few launches --------------------------
     npair = min(K, 50)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(npair)]
     for i in range(npair):
         ev[i][0].record(stream)
-        step(i)
+        wl.step(i)
         ev[i][1].record(stream)
     torch.cuda.synchronize(dev)
     pair_ms = sorted(s.elapsed_time(e) for s, e in ev)
-    kern_ms_pair_med = pair_ms[npair // 2]
+    kern_ms_pair_med = pair_ms[npair // 2] / wl.launches_per_step
 
-    # ---- measured streaming ceiling on the same buffers (untimed): plain 16 B/lane non-temporal copy --------
+    # ---- measured streaming ceiling on the same buffers (untimed): plain 16 B/lane non-temporal copy ----
     copy_gbs = None
-    if world == 1 and nring >= 2 and (ins[0].numel() % 4 == 0):
+    if world == 1 and wl.nring >= 2 and (wl.ins[0].numel() % 4 == 0):
+        lib, sh, nring = wl.lib, wl.sh, wl.nring
         ncopy = 200
-        npx = ins[0].numel()
+        npx = wl.ins[0].numel()
         for i in range(20):
-            lib.csic_copy_device(in_ptrs[(i + 1) % nring], in_ptrs[i % nring], npx, sh)
+            lib.csic_copy_device(wl.in_ptrs[(i + 1) % nring], wl.in_ptrs[i % nring], npx, sh)
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c0.record(stream)
         for i in range(ncopy):
-            lib.csic_copy_device(in_ptrs[(i + 1) % nring], in_ptrs[i % nring], npx, sh)
+            lib.csic_copy_device(wl.in_ptrs[(i + 1) % nring], wl.in_ptrs[i % nring], npx, sh)
         c1.record(stream)
         torch.cuda.synchronize(dev)
         copy_gbs = 2.0 * npx * 4 * ncopy / (c0.elapsed_time(c1) * 1e-3) / 1e9
 
-    total_px = world * in_px * fps * K if args.scaling == "weak" else in_px * fps * K * world
-    value = total_px / elapsed / 1e6
-    achieved = alg_bytes / (kern_ms_avg * 1e-3) / 1e9
+    # ---- the same K steps through the direct-dispatch engine (side measurement, every N) ---------------
+    direct = None
+    if not args.no_direct and args.streams <= 1 and (wl.fps == 1 or wl.per_frame_graph):
+        eld = timed_direct(wl, args, torch, dist, world, args.backend, dev)
+        pxd = allsum(float(wl.in_px) * wl.fps * K)
+        per_launch_ms = eld * 1e3 / K / wl.launches_per_step
+        direct = {"value": round(pxd / eld / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(eld * 1e3 / K, 5), "steps": K,
+                  "scaling": headline_mode, "launch": wl.direct_desc,
+                  "roofline_frac_rank0": round(wl.alg_bytes / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  "note": "same plan, same ring, same kernels as the headline; `value` above is the HIP-stream path, this is "
+                          "what csic_frame_graph_submit/_wait deliver for a pre-recorded stream of frames"}
+
+    head = {"stripe_rows": wl.stripe_rows, "global_rows": wl.global_rows, "nring": wl.nring, "kernel": wl.plan.kernel_name,
+            "launch": wl.launch_desc, "alg_bytes": wl.alg_bytes, "lpf": wl.lpf, "out_px": wl.out_px, "in_px": wl.in_px,
+            "fps": wl.fps}
+    wl.close()
+
+    # ---- N > 1: the other scaling mode, measured in the same process, reported beside the headline ----
+    other = None
+    if world > 1 and args.scaling in ("strong", "both", "weak"):
+        omode = "weak" if headline_mode == "strong" else "strong"
+        wl2 = Workload(args, csic, torch, dev, dev_index, world, rank, omode)
+        el2, km2 = timed_run(wl2, args, torch, dist, world, args.backend, dev)
+        px2 = allsum(float(wl2.in_px) * wl2.fps * K)
+        other = {"scaling": omode, "value": round(px2 / el2 / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(el2 * 1e3 / K, 5),
+                 "stripe_rows_per_gpu": wl2.stripe_rows, "global_rows": wl2.global_rows, "launch": wl2.launch_desc,
+                 "roofline_frac_rank0": round(wl2.alg_bytes / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "kernel_ms_avg_rank0": round(km2, 5)}
+        wl2.close()
 
     if rank == 0:
-        traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                ent = json.load(open(tpath)).get(args.config)
-                if ent and ent.get("plan_kernel") == plan.kernel_name and world == 1:
-                    traffic, traffic_note = ent["hbm_bytes_per_launch"], f"profiles/pmc_traffic.json ({ent['tag']}): " + ent["note"]
-            except Exception:
-                pass
+        traffic, traffic_note = load_traffic(args.config, head["kernel"], world)
+        if args.frames_per_step > 0 or args.order != "csq" or args.per_frame_graph or args.block_threads or args.variant >= 0 or args.no_vector:
+            traffic, traffic_note = None, "PMC entries are for the default launch of each config only"
+        lpf, out_px, in_px = head["lpf"], head["out_px"], head["in_px"]
+        order_txt = "chroma->spatial->quant" if args.order == "csq" else "spatial->chroma->quant"
         line = {
             "metric": "Mpixels/s end-to-end (RGB->YCbCr->4:2:0->reconstruct)",
             "value": round(value, 1), "unit": "Mpixels/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / K, 5),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "higher_is_better": True, "scaling": headline_mode, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: {W}x{H} ARGB, 4:{a}:{b}, bits {bits[0]}/{bits[1]}/{bits[2]}, sf={f}, "
-                            f"order chroma->spatial->quant, {fps} frame(s)/step, FLOOR_HW",
-                "stripe_rows_per_gpu": sH, "global_rows": gH, "ring_frames": nring, "prewarm_ms": args.prewarm_ms,
-                "parallelism": f"row-stripe x{world}, no collective",
-                "kernel": plan.kernel_name,
-                "launch": ("hipGraph of %d per-frame launches" % fps) if launches_per_step > 1 else "one launch per step",
+                            f"order {order_txt}, {head['fps']} frame(s)/step, FLOOR_HW",
+                "stripe_rows_per_gpu": head["stripe_rows"], "global_rows": head["global_rows"], "ring_frames": head["nring"],
+                "prewarm_ms": args.prewarm_ms,
+                "parallelism": f"row-stripe x{world}, no data-path collective",
+                "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else " (rehearsal: ranks share one GPU)")) if world > 1 else "none (single process)",
+                "world_size_formed": formed,
+                "kernel": head["kernel"],
+                "launch": head["launch"],
                 "streams": args.streams,
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes,
+                "traffic_source": traffic_note,
+                "algorithmic_bytes_per_launch": head["alg_bytes"],
                 # the stricter and the stream-everything byte models, for comparison only
                 "algorithmic_bytes_strict": 8 * out_px * lpf, "algorithmic_bytes_full": (4 * in_px + 4 * out_px) * lpf,
                 "kernel_ms_avg": round(kern_ms_avg, 5),
                 "kernel_ms_event_pair_median": round(kern_ms_pair_med, 5),
-                "timing": "kernel_ms_avg = (HIP event after launch K - HIP event before launch 1) / K on the launch "
-                          "stream (torch current stream), inside the timed region; event_pair_median = untimed "
-                          "diagnostic, one event pair per launch (inflated by the marker packets)",
+                "timing": "kernel_ms_avg = (HIP event after step K - HIP event before step 1) / launches on the launch "
+                          "stream (torch current stream), inside the timed region, rank 0; event_pair_median = untimed "
+                          "diagnostic, one event pair per step (inflated by the marker packets)",
             },
         }
-        if traffic_note:
-            line["roofline"]["traffic_source"] = traffic_note
+        if other is not None:
+            line[other["scaling"]] = other
+        if direct is not None:
+            line["direct_dispatch"] = direct
         if copy_gbs:
             line["roofline"]["copy_ceiling"] = {
                 "GB/s": round(copy_gbs, 1), "frac_of_peak": round(copy_gbs / HBM_PEAK_GBS, 4),
@@ -348,7 +588,6 @@ def main():
             line["cpu_baseline"] = cpu_baseline(W, H, a, b, bits, f, args.cpu_budget)
         print(json.dumps(line), flush=True)
 
-    plan.close()
     if world > 1:
         dist.destroy_process_group()
 

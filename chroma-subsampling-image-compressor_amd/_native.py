@@ -20,7 +20,8 @@ OP_NOOP, OP_SPATIAL, OP_QUANT, OP_CHROMA = 0, 1, 2, 3
 ROUND_FLOOR_HW, ROUND_TRUNC_SW = 0, 1
 FMT_ARGB8888, FMT_YCBCR888X = 0, 1
 TUNE_VARIANT, TUNE_FORCE_GENERIC, TUNE_NONTEMPORAL, TUNE_NO_VECTOR, TUNE_BLOCK_THREADS = 1, 2, 3, 4, 5
-FRAME_GRAPH_DEFAULT_BRANCHES = 8
+FRAME_GRAPH_HIP, FRAME_GRAPH_DIRECT = 0, 1
+FRAME_GRAPH_DEFAULT_BRANCHES, FRAME_GRAPH_DEFAULT_QUEUES = 4, 4
 PIPELINE_STAGED, PIPELINE_ZERO_COPY = 0, 1
 
 
@@ -88,6 +89,11 @@ PROTOTYPES = {
     "csic_checksum_device": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64), C.c_void_p]),
     "csic_frame_graph_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                                           C.POINTER(C.c_void_p)]),
+    "csic_frame_graph_create_ex": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
+                                             C.c_int32, C.POINTER(C.c_void_p)]),
+    "csic_frame_graph_submit": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "csic_frame_graph_wait": (C.c_int, [C.c_void_p, C.c_int64]),
+    "csic_frame_graph_backend": (C.c_int, [C.c_void_p]),
     "csic_frame_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "csic_frame_graph_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "csic_frame_graph_destroy": (C.c_int, [C.c_void_p]),

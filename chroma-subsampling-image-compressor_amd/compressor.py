@@ -126,39 +126,56 @@ class Plan:
 
 
 class FrameGraph:
-    """Per-frame launches of one plan captured in a hipGraph (csic_frame_graph_*; BASELINE.json configs[4]).
+    """Pre-recorded per-frame launches of one plan (csic_frame_graph_*; BASELINE.json configs[4]).
 
     `d_ins[k]` / `d_outs[k]` are CUDA tensors holding frame k's W*H input pixels / receiving its Wo*Ho output
     pixels; they may live anywhere on the plan's device (views into one big tensor, or separate allocations).
-    `branches` independent dependency chains let that many frame kernels overlap (1 = the strictly serial
-    graph that capturing a loop on one stream gives; None = library default)."""
+    backend "hip": `branches` hipGraph chains, launch(stream) is asynchronous and ordered with the stream.
+    backend "direct": AQL packets without barrier bits on the library's own user-mode queues (`branches` =
+    queues); submit() starts immediately and returns a ticket, wait() blocks the host; launch(stream) is the
+    synchronous composition stream-sync + submit + wait."""
 
-    def __init__(self, plan: Plan, d_ins, d_outs, branches=None):
+    BACKENDS = {"hip": N.FRAME_GRAPH_HIP, "direct": N.FRAME_GRAPH_DIRECT}
+
+    def __init__(self, plan: Plan, d_ins, d_outs, branches=None, backend: str = "hip"):
         n = len(d_ins)
         if n != len(d_outs) or n == 0:
             raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: need as many output as input frames (> 0)")
+        if backend not in self.BACKENDS:
+            raise N.IllegalArgumentException(N.EINVAL_SIZE, f"requirement failed: backend must be one of {sorted(self.BACKENDS)}")
         for t_in, t_out in zip(d_ins, d_outs):
             if t_in.numel() != plan.width * plan.height or t_out.numel() != plan.out_width * plan.out_height \
                     or t_in.element_size() != 4 or t_out.element_size() != 4 \
                     or not t_in.is_contiguous() or not t_out.is_contiguous() \
                     or t_in.device.index != plan.device or t_out.device.index != plan.device:
                 raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: frame tensor has the wrong size/layout/device")
-        self.plan, self.device = plan, plan.device
+        self.plan, self.device, self.backend = plan, plan.device, backend
         self._keep = (list(d_ins), list(d_outs))              # the graph holds raw pointers
         pin = (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) for t in d_ins])
         pout = (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) for t in d_outs])
         self._h = C.c_void_p()
-        N.check(N.lib().csic_frame_graph_create(plan._h, pin, pout, n, 0 if branches is None else int(branches),
-                                                C.byref(self._h)))
+        N.check(N.lib().csic_frame_graph_create_ex(plan._h, pin, pout, n, 0 if branches is None else int(branches),
+                                                   self.BACKENDS[backend], C.byref(self._h)))
         nf, nb = C.c_int32(), C.c_int32()
         N.check(N.lib().csic_frame_graph_count(self._h, C.byref(nf), C.byref(nb)))
         self.nframes, self.branches = nf.value, nb.value
 
     def launch(self, stream=None) -> None:
-        """Replays the graph on `stream` (a torch.cuda.Stream; default: torch's current stream).  Asynchronous."""
+        """Replays the graph on `stream` (a torch.cuda.Stream; default: torch's current stream).  Asynchronous for
+        the "hip" backend, host-synchronous for "direct"."""
         import torch
         s = torch.cuda.current_stream(self.device) if stream is None else stream
         N.check(N.lib().csic_frame_graph_launch(self._h, C.c_void_p(s.cuda_stream)))
+
+    def submit(self) -> int:
+        """backend "direct": start all frames now (inputs must be ready); returns a ticket for wait()."""
+        t = C.c_int64()
+        N.check(N.lib().csic_frame_graph_submit(self._h, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket: int = -1) -> None:
+        """backend "direct": block until submission `ticket` (default: every submission so far) has finished."""
+        N.check(N.lib().csic_frame_graph_wait(self._h, ticket))
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -1,88 +1,589 @@
-// csic_graph.hip -- BASELINE.json configs[4]: "hipGraph-captured per-frame launch".
+// csic_graph.hip -- pre-recorded per-frame launches (BASELINE.json configs[4]: "hipGraph-captured per-frame launch")
+// and the launch engine behind them.
 //
-// One kernel node per frame, built with the explicit graph API (no stream capture, no helper streams):
-// the launch descriptor of every frame comes from the same prepare_launch() that csic_process_device uses,
-// so a replayed node is bit-for-bit the eager launch.  Frames are independent images (the reference builds
-// a fresh DUT per image, ImageCompressorTopApp.scala:53-68), so the graph keeps only `branches` chains of
-// dependencies: with one chain every node waits for its predecessor's completion signal (the dependent-kernel
-// boundary, ~1.7 us -- half of a 4K sf=4 frame's 4.2 us), with B chains the runtime overlaps B frames.
+// A frame of cfg 5 (3840x2160, sf=4) is 10.4 MB = 1.3 us of HBM time; a strong-scaling stripe of cfg 4 on 8 GPUs
+// (8192x1024) is 25 MB = 3.1 us.  Launched one after the other on a HIP stream -- eagerly or from a captured
+// hipGraph, it makes no difference -- every launch also pays the dependent-kernel boundary (~1.7 us: the AQL
+// barrier bit drains the previous kernel before the next one may start) and the command processor's per-packet
+// front end.  Measured on MI355X (profiles/r02_small_launch.md), per cfg 5 frame:
+//     hipGraph, one chain                     3.65 us   35 % of the HBM roofline      <- what round 1 shipped
+//     one hipGraph with parallel branches     3.1-4.2   ROCm replays it node by node from the host (3.1 us of host
+//                                                       time per node): slower than the chain
+//     3 chain graphs on 3 streams             2.9 us    44 %                           <- CSIC_FRAME_GRAPH_HIP
+//     AQL packets, no barrier bit, 1 queue    2.8 us    46 %   (the CP front end is serial per queue)
+//     AQL packets, no barrier bit, 4 queues   1.76 us   74 %                           <- CSIC_FRAME_GRAPH_DIRECT
+//     one batched launch of all 64 frames     1.75 us   74 %   (needs contiguous frames)
+//
+// Two backends therefore:
+//  * CSIC_FRAME_GRAPH_HIP: `branches` hipGraph CHAINS (explicit kernel nodes from prepare_launch(), so a node is
+//    bit for bit the eager launch), chain 0 replayed on the caller's stream and the others on internal streams,
+//    forked and joined with events -- fully ordered with the caller's stream, works under stream capture rules of
+//    plain HIP.
+//  * CSIC_FRAME_GRAPH_DIRECT: the same launches as pre-built AQL kernel-dispatch packets, copied into `nq` user-mode
+//    HSA queues owned by the library (frame k -> queue k % nq) WITHOUT the barrier bit, so consecutive frames
+//    overlap like the workgroups of one big launch; the first packet of a submission on each queue carries the
+//    barrier bit and an agent-scope acquire, a closing barrier-AND packet per queue carries the release and the
+//    completion signal.  The kernels are the ones HIP loaded: their kernel objects are found among the process's
+//    loaded executables (hsa_ven_amd_loader_iterate_executables) under the name hipKernelNameRefByPtr reports.
+//    These queues are not HIP streams: a submission starts immediately and is awaited on the host
+//    (csic_frame_graph_submit / _wait); csic_frame_graph_launch() on a DIRECT graph is the synchronous
+//    composition stream-sync + submit + wait.
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <hsa/hsa_ven_amd_loader.h>
+
+#include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "csic_hip_common.h"
 
-struct csic_frame_graph {
-    int device = 0;
-    int32_t nframes = 0, branches = 0;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+namespace csic {
+
+#define HSA_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hsa_status_t s_ = (expr);                                                                \
+        if (s_ != HSA_STATUS_SUCCESS && s_ != HSA_STATUS_INFO_BREAK) {                           \
+            const char *m_ = nullptr;                                                            \
+            (void)hsa_status_string(s_, &m_);                                                    \
+            return ::csic::set_error(CSIC_EHIP, "%s failed: %s", #expr, m_ ? m_ : "unknown HSA status"); \
+        }                                                                                        \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// DirectEngine: `nq` user-mode AQL queues on one device, shared by every DIRECT graph of that device
+// ------------------------------------------------------------------------------------------------
+constexpr int MAX_QUEUES = 8;
+constexpr uint32_t QUEUE_PACKETS = 4096;       // ring size per queue (packets of 64 B)
+constexpr uint64_t WAIT_TICKS = 3000000000ull; // ~30 s at the 100 MHz system clock: a wait that long is an error, not a hang
+
+struct KernelInfo {
+    uint64_t object = 0;
+    uint32_t kernarg_size = 0;
 };
+
+struct DirectEngine {
+    int device = -1;
+    hsa_agent_t agent{};
+    int nq = 0;
+    hsa_queue_t *q[MAX_QUEUES] = {};
+    std::mutex mu;                              // serialises submissions (ring reservations stay contiguous per queue)
+    std::map<const void *, KernelInfo> kernels; // host stub address -> kernel object
+    int refs = 0;
+};
+
+static std::mutex g_engines_mu;
+static std::map<int, DirectEngine *> g_engines;
+
+struct AgentSearch {
+    uint32_t want_bdf, want_domain;
+    bool by_bdf;
+    int want_ordinal, seen;
+    hsa_agent_t agent;
+    bool found;
+};
+
+static hsa_status_t agent_cb(hsa_agent_t a, void *data)
+{
+    AgentSearch *s = static_cast<AgentSearch *>(data);
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS || t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    uint32_t bdf = 0, domain = 0;
+    (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+    (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+    const bool hit = s->by_bdf ? (bdf == s->want_bdf && domain == s->want_domain) : (s->seen == s->want_ordinal);
+    s->seen += 1;
+    if (hit) { s->agent = a; s->found = true; return HSA_STATUS_INFO_BREAK; }
+    return HSA_STATUS_SUCCESS;
+}
+
+// HIP device ordinal -> HSA agent, by PCI address (robust against *_VISIBLE_DEVICES reorderings); by GPU ordinal
+// if the PCI attributes are not available.
+static int find_agent(int device, hsa_agent_t *out)
+{
+    int bus = -1, dev = -1, dom = 0;
+    AgentSearch s{};
+    s.by_bdf = hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) == hipSuccess &&
+               hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, device) == hipSuccess && bus >= 0 && dev >= 0;
+    if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainId, device) != hipSuccess) dom = 0;
+    s.want_bdf = ((uint32_t)bus << 8) | ((uint32_t)dev << 3);
+    s.want_domain = (uint32_t)dom;
+    s.want_ordinal = device;
+    HSA_TRY(hsa_iterate_agents(agent_cb, &s));
+    if (!s.found && s.by_bdf) {                 // BDF layouts differ on some hosts: fall back to the ordinal
+        s.by_bdf = false; s.seen = 0;
+        HSA_TRY(hsa_iterate_agents(agent_cb, &s));
+    }
+    if (!s.found) return set_error(CSIC_ENODEVICE, "no HSA GPU agent matches HIP device %d", device);
+    *out = s.agent;
+    return CSIC_OK;
+}
+
+static void engine_free(DirectEngine *e)
+{
+    for (int i = 0; i < e->nq; ++i)
+        if (e->q[i]) (void)hsa_queue_destroy(e->q[i]);
+    delete e;
+    (void)hsa_shut_down();                      // reference counted by the runtime; HIP keeps its own reference
+}
+
+// creates queues until the engine has `nq` of them (never destroys one while the engine lives)
+static int engine_grow(DirectEngine *e, int nq)
+{
+    for (int i = e->nq; i < nq; ++i) {
+        hsa_status_t s = hsa_queue_create(e->agent, QUEUE_PACKETS, HSA_QUEUE_TYPE_MULTI, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &e->q[i]);
+        if (s != HSA_STATUS_SUCCESS) {
+            const char *m = nullptr;
+            (void)hsa_status_string(s, &m);
+            return set_error(CSIC_EHIP, "hsa_queue_create (queue %d of %d) failed: %s", i, nq, m ? m : "?");
+        }
+        e->nq = i + 1;
+    }
+    return CSIC_OK;
+}
+
+static int engine_acquire(int device, int nq, DirectEngine **out)
+{
+    std::lock_guard<std::mutex> lk(g_engines_mu);
+    auto it = g_engines.find(device);
+    if (it != g_engines.end()) {
+        DirectEngine *e = it->second;
+        {
+            std::lock_guard<std::mutex> lk2(e->mu);
+            int st = engine_grow(e, nq);
+            if (st != CSIC_OK) return st;
+        }
+        e->refs += 1;
+        *out = e;
+        return CSIC_OK;
+    }
+    HSA_TRY(hsa_init());
+    DirectEngine *e = new (std::nothrow) DirectEngine();
+    if (!e) { (void)hsa_shut_down(); return set_error(CSIC_ENOMEM, "out of host memory"); }
+    e->device = device;
+    int st = find_agent(device, &e->agent);
+    if (st == CSIC_OK) st = engine_grow(e, nq);
+    if (st != CSIC_OK) { engine_free(e); return st; }
+    e->refs = 1;
+    g_engines[device] = e;
+    *out = e;
+    return CSIC_OK;
+}
+
+static void engine_release(DirectEngine *e)
+{
+    std::lock_guard<std::mutex> lk(g_engines_mu);
+    if (--e->refs > 0) return;
+    g_engines.erase(e->device);
+    engine_free(e);
+}
+
+struct SymbolSearch {
+    hsa_agent_t agent;
+    std::string want;
+    KernelInfo info;
+    uint32_t group = 0, priv = 0;
+    bool found = false;
+};
+
+static hsa_status_t symbol_cb(hsa_executable_t, hsa_agent_t, hsa_executable_symbol_t sym, void *data)
+{
+    SymbolSearch *s = static_cast<SymbolSearch *>(data);
+    hsa_symbol_kind_t kind;
+    if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_TYPE, &kind) != HSA_STATUS_SUCCESS || kind != HSA_SYMBOL_KIND_KERNEL)
+        return HSA_STATUS_SUCCESS;
+    uint32_t len = 0;
+    if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_NAME_LENGTH, &len) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    std::string name(len, '\0');
+    if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_NAME, &name[0]) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (name != s->want && name != s->want + ".kd") return HSA_STATUS_SUCCESS;
+    (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &s->info.object);
+    (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &s->info.kernarg_size);
+    (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &s->group);
+    (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &s->priv);
+    s->found = true;
+    return HSA_STATUS_INFO_BREAK;
+}
+
+static hsa_status_t executable_cb(hsa_executable_t ex, void *data)
+{
+    SymbolSearch *s = static_cast<SymbolSearch *>(data);
+    (void)hsa_executable_iterate_agent_symbols(ex, s->agent, symbol_cb, data);
+    return s->found ? HSA_STATUS_INFO_BREAK : HSA_STATUS_SUCCESS;
+}
+
+// Kernel object of the HIP kernel behind host stub `fn` on the engine's device.
+static int engine_kernel(DirectEngine *e, KernelFn fn, KernelInfo *out)
+{
+    const void *key = reinterpret_cast<const void *>(fn);
+    auto it = e->kernels.find(key);
+    if (it != e->kernels.end()) { *out = it->second; return CSIC_OK; }
+    hipFuncAttributes attr;
+    HIP_TRY(hipFuncGetAttributes(&attr, key));              // forces HIP to load the code object on this device
+    const char *name = hipKernelNameRefByPtr(key, nullptr);
+    if (!name || !*name) return set_error(CSIC_EHIP, "hipKernelNameRefByPtr gave no name for the selected kernel");
+    hsa_ven_amd_loader_1_03_pfn_t loader;
+    std::memset(&loader, 0, sizeof loader);
+    HSA_TRY(hsa_system_get_major_extension_table(HSA_EXTENSION_AMD_LOADER, 1, sizeof loader, &loader));
+    if (!loader.hsa_ven_amd_loader_iterate_executables)
+        return set_error(CSIC_EHIP, "this ROCm runtime has no hsa_ven_amd_loader_iterate_executables");
+    SymbolSearch s;
+    s.agent = e->agent;
+    s.want = name;
+    HSA_TRY(loader.hsa_ven_amd_loader_iterate_executables(executable_cb, &s));
+    if (!s.found) return set_error(CSIC_EHIP, "kernel %s not found among the loaded executables", name);
+    if (s.group != 0 || s.priv != 0)
+        return set_error(CSIC_EHIP, "kernel %s uses LDS/scratch (%u/%u B): not dispatchable by the direct engine", name, s.group, s.priv);
+    if (s.info.kernarg_size < sizeof(KArgs))
+        return set_error(CSIC_EHIP, "kernel %s: kernarg segment %u B smaller than KArgs (%zu B)", name, s.info.kernarg_size, sizeof(KArgs));
+    e->kernels[key] = s.info;
+    *out = s.info;
+    return CSIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// internal streams of the HIP backend: ONE pool per device, shared by every graph.  The device has 4 hardware
+// queues (GPU_MAX_HW_QUEUES); if every graph brought its own streams, a ring of graphs would oversubscribe them
+// (4 graphs x 3 own streams: 4.1 us per cfg 5 frame instead of 3.0 us).  Streams are created on first use and
+// live until the process ends.
+// ------------------------------------------------------------------------------------------------
+static std::mutex g_streams_mu;
+static std::map<int, std::vector<hipStream_t>> g_streams;
+
+static int pooled_stream(int device, int idx, hipStream_t *out)
+{
+    std::lock_guard<std::mutex> lk(g_streams_mu);
+    std::vector<hipStream_t> &v = g_streams[device];
+    while ((int)v.size() <= idx) {
+        hipStream_t s = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        v.push_back(s);
+    }
+    *out = v[idx];
+    return CSIC_OK;
+}
+
+} // namespace csic
 
 using namespace csic;
 
+// ------------------------------------------------------------------------------------------------
+// the graph object
+// ------------------------------------------------------------------------------------------------
+constexpr int DIRECT_SLOTS = 16;               // submissions that may be outstanding per DIRECT graph
+
+struct csic_frame_graph {
+    int device = 0;
+    int32_t backend = CSIC_FRAME_GRAPH_HIP;
+    int32_t nframes = 0, branches = 0;
+    // HIP backend: one chain graph per branch; chain 0 runs on the caller's stream
+    std::vector<hipGraph_t> graphs;
+    std::vector<hipGraphExec_t> execs;
+    std::vector<hipStream_t> streams;           // streams[i] serves chain i (streams[0] unused); borrowed from the device's pool
+    std::vector<hipEvent_t> joins;
+    hipEvent_t fork = nullptr;
+    // DIRECT backend
+    DirectEngine *eng = nullptr;
+    void *d_kernarg = nullptr;
+    std::vector<hsa_kernel_dispatch_packet_t> packets[MAX_QUEUES];   // templates, header left INVALID
+    hsa_signal_t done[DIRECT_SLOTS][MAX_QUEUES] = {};
+    bool have_signals = false;
+    int64_t next_ticket = 0, waited = 0;        // tickets < waited have completed and been observed
+};
+
 static void graph_free(csic_frame_graph *g)
 {
-    if (g->exec) (void)hipGraphExecDestroy(g->exec);
-    if (g->graph) (void)hipGraphDestroy(g->graph);
+    for (auto ex : g->execs) if (ex) (void)hipGraphExecDestroy(ex);
+    for (auto gr : g->graphs) if (gr) (void)hipGraphDestroy(gr);
+    for (auto ev : g->joins) if (ev) (void)hipEventDestroy(ev);
+    if (g->fork) (void)hipEventDestroy(g->fork);
+    for (auto s : g->streams) if (s) (void)hipStreamSynchronize(s);        // pooled: not destroyed here
+    if (g->d_kernarg) (void)hipFree(g->d_kernarg);
+    if (g->have_signals)
+        for (int s = 0; s < DIRECT_SLOTS; ++s)
+            for (int j = 0; j < MAX_QUEUES; ++j)
+                if (g->done[s][j].handle) (void)hsa_signal_destroy(g->done[s][j]);
+    if (g->eng) engine_release(g->eng);
     delete g;
+}
+
+static int build_hip(csic_frame_graph *g, csic_plan *plan, const void *const *d_in, void *const *d_out)
+{
+    const int B = g->branches, n = g->nframes;
+    try {
+        g->graphs.assign(B, nullptr); g->execs.assign(B, nullptr); g->streams.assign(B, nullptr); g->joins.assign(B, nullptr);
+    } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
+    for (int i = 0; i < B; ++i) {
+        HIP_TRY(hipGraphCreate(&g->graphs[i], 0));
+        hipGraphNode_t prev{};
+        bool have = false;
+        for (int k = i; k < n; k += B) {
+            LaunchDesc d;
+            int st = prepare_launch(plan, d_in[k], d_out[k], 1, 0, 0, &d);
+            if (st != CSIC_OK) return st;
+            void *params[1] = {&d.args};                       // copied by hipGraphAddKernelNode
+            hipKernelNodeParams np;
+            std::memset(&np, 0, sizeof np);
+            np.func = reinterpret_cast<void *>(d.fn);
+            np.gridDim = d.grid;
+            np.blockDim = d.block;
+            np.kernelParams = params;
+            hipGraphNode_t node;
+            HIP_TRY(hipGraphAddKernelNode(&node, g->graphs[i], have ? &prev : nullptr, have ? 1 : 0, &np));
+            prev = node;
+            have = true;
+        }
+        HIP_TRY(hipGraphInstantiate(&g->execs[i], g->graphs[i], nullptr, nullptr, 0));
+        if (i > 0) {
+            int st = pooled_stream(g->device, i - 1, &g->streams[i]);
+            if (st != CSIC_OK) return st;
+            HIP_TRY(hipEventCreateWithFlags(&g->joins[i], hipEventDisableTiming));
+        }
+    }
+    if (B > 1) HIP_TRY(hipEventCreateWithFlags(&g->fork, hipEventDisableTiming));
+    return CSIC_OK;
+}
+
+static int build_direct(csic_frame_graph *g, csic_plan *plan, const void *const *d_in, void *const *d_out)
+{
+    const int n = g->nframes;
+    int st = engine_acquire(g->device, g->branches, &g->eng);
+    if (st != CSIC_OK) return st;
+    DirectEngine *e = g->eng;
+    std::lock_guard<std::mutex> lk(e->mu);
+    // resolve every node first (kernarg sizes may differ if some frames fall back to the 4-byte kernels)
+    std::vector<LaunchDesc> descs;
+    std::vector<KernelInfo> infos;
+    try { descs.resize(n); infos.resize(n); } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
+    size_t stride = 0;
+    for (int k = 0; k < n; ++k) {
+        st = prepare_launch(plan, d_in[k], d_out[k], 1, 0, 0, &descs[k]);
+        if (st != CSIC_OK) return st;
+        st = engine_kernel(e, descs[k].fn, &infos[k]);
+        if (st != CSIC_OK) return st;
+        const size_t need = (infos[k].kernarg_size + 255u) & ~size_t(255);
+        if (need > stride) stride = need;
+    }
+    // kernarg blocks in device memory (what HIP does on this part too): the explicit KArgs, then the implicit
+    // arguments of code-object v5 -- zero except block counts and group sizes (the shipped kernels read none)
+    std::vector<uint8_t> host;
+    try { host.assign(stride * n, 0); } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
+    const size_t hidden = (sizeof(KArgs) + 7) & ~size_t(7);
+    for (int k = 0; k < n; ++k) {
+        uint8_t *b = host.data() + (size_t)k * stride;
+        std::memcpy(b, &descs[k].args, sizeof(KArgs));
+        if (hidden + 18 <= infos[k].kernarg_size) {
+            const uint32_t bc[3] = {descs[k].grid.x, descs[k].grid.y, descs[k].grid.z};
+            const uint16_t gs[3] = {(uint16_t)descs[k].block.x, (uint16_t)descs[k].block.y, (uint16_t)descs[k].block.z};
+            std::memcpy(b + hidden, bc, 12);
+            std::memcpy(b + hidden + 12, gs, 6);
+        }
+    }
+    HIP_TRY(hipMalloc(&g->d_kernarg, host.size()));
+    HIP_TRY(hipMemcpy(g->d_kernarg, host.data(), host.size(), hipMemcpyHostToDevice));
+    for (int k = 0; k < n; ++k) {
+        hsa_kernel_dispatch_packet_t p;
+        std::memset(&p, 0, sizeof p);
+        const LaunchDesc &d = descs[k];
+        p.workgroup_size_x = (uint16_t)d.block.x; p.workgroup_size_y = (uint16_t)d.block.y; p.workgroup_size_z = (uint16_t)d.block.z;
+        p.grid_size_x = d.grid.x * d.block.x; p.grid_size_y = d.grid.y * d.block.y; p.grid_size_z = d.grid.z * d.block.z;
+        p.kernel_object = infos[k].object;
+        p.kernarg_address = static_cast<uint8_t *>(g->d_kernarg) + (size_t)k * stride;
+        try { g->packets[k % g->branches].push_back(p); } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
+    }
+    for (int s = 0; s < DIRECT_SLOTS; ++s)
+        for (int j = 0; j < g->branches; ++j) {
+            g->have_signals = true;
+            HSA_TRY(hsa_signal_create(0, 0, nullptr, &g->done[s][j]));
+        }
+    return CSIC_OK;
+}
+
+// header word = 16-bit AQL header | 16-bit setup, published last with release semantics
+static inline void publish(void *slot, uint16_t header, uint16_t setup)
+{
+    __atomic_store_n(static_cast<uint32_t *>(slot), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
+}
+
+static int wait_slot(csic_frame_graph *g, int64_t ticket)
+{
+    const int slot = (int)(ticket % DIRECT_SLOTS);
+    for (int j = 0; j < g->branches; ++j) {
+        const hsa_signal_value_t v = hsa_signal_wait_scacquire(g->done[slot][j], HSA_SIGNAL_CONDITION_LT, 1, WAIT_TICKS, HSA_WAIT_STATE_BLOCKED);
+        if (v >= 1) return set_error(CSIC_EHIP, "direct dispatch: queue %d did not finish submission %lld in time", j, (long long)ticket);
+    }
+    return CSIC_OK;
+}
+
+static int direct_wait(csic_frame_graph *g, int64_t ticket)
+{
+    if (ticket < 0 || ticket >= g->next_ticket) ticket = g->next_ticket - 1;
+    while (g->waited <= ticket) {
+        int st = wait_slot(g, g->waited);
+        if (st != CSIC_OK) return st;
+        g->waited += 1;
+    }
+    return CSIC_OK;
+}
+
+static int direct_submit(csic_frame_graph *g, int64_t *ticket)
+{
+    DirectEngine *e = g->eng;
+    if (g->next_ticket - g->waited >= DIRECT_SLOTS) {           // recycle the oldest slot: the host waits for it
+        int st = direct_wait(g, g->waited);
+        if (st != CSIC_OK) return st;
+    }
+    const int64_t t = g->next_ticket;
+    const int slot = (int)(t % DIRECT_SLOTS);
+    std::lock_guard<std::mutex> lk(e->mu);
+    const int nq = g->branches;                                 // this graph's queues: the engine's first `nq`
+    for (int j = 0; j < nq; ++j) hsa_signal_store_relaxed(g->done[slot][j], 1);
+    const uint16_t setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+    const uint16_t h_first = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                             (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE);
+    const uint16_t h_next = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE);      // no barrier bit, no fences
+    const uint16_t h_close = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                             (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    // Queues are filled in lock step, a chunk at a time, so that a graph larger than the rings flows through them.
+    const uint32_t CHUNK = 512;
+    size_t pos[MAX_QUEUES] = {};
+    bool closed[MAX_QUEUES] = {};
+    int open = nq;
+    while (open > 0) {
+        for (int j = 0; j < nq; ++j) {
+            if (closed[j]) continue;
+            hsa_queue_t *q = e->q[j];
+            const size_t left = g->packets[j].size() - pos[j];
+            const uint32_t nk = (uint32_t)(left < CHUNK ? left : CHUNK);
+            const bool last = (left == nk);
+            const uint32_t total = nk + (last ? 1u : 0u);
+            const uint64_t idx = hsa_queue_add_write_index_relaxed(q, total);
+            // flow control: the reserved range must fit in the ring behind the read index
+            for (uint64_t spins = 0; idx + total - hsa_queue_load_read_index_scacquire(q) > q->size; ++spins)
+                if (spins > 2000000000ull) return set_error(CSIC_EHIP, "direct dispatch: queue %d is not draining", j);
+            auto *ring = static_cast<hsa_kernel_dispatch_packet_t *>(q->base_address);
+            const uint64_t mask = q->size - 1;
+            for (uint32_t i = 0; i < nk; ++i) {
+                hsa_kernel_dispatch_packet_t *dst = &ring[(idx + i) & mask];
+                const hsa_kernel_dispatch_packet_t &src = g->packets[j][pos[j] + i];
+                std::memcpy(reinterpret_cast<uint8_t *>(dst) + 4, reinterpret_cast<const uint8_t *>(&src) + 4, sizeof src - 4);
+                publish(dst, (pos[j] + i == 0) ? h_first : h_next, setup);
+            }
+            if (last) {
+                auto *bp = reinterpret_cast<hsa_barrier_and_packet_t *>(&ring[(idx + nk) & mask]);
+                std::memset(reinterpret_cast<uint8_t *>(bp) + 4, 0, sizeof *bp - 4);
+                bp->completion_signal = g->done[slot][j];
+                publish(bp, h_close, 0);
+                closed[j] = true;
+                open -= 1;
+            }
+            pos[j] += nk;
+            hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx + total - 1));
+        }
+    }
+    g->next_ticket = t + 1;
+    if (ticket) *ticket = t;
+    return CSIC_OK;
 }
 
 extern "C" {
 
-int csic_frame_graph_create(csic_plan *plan, const void *const *d_in, void *const *d_out, int32_t nframes,
-                            int32_t branches, csic_frame_graph **out)
+int csic_frame_graph_create_ex(csic_plan *plan, const void *const *d_in, void *const *d_out, int32_t nframes,
+                               int32_t branches, int32_t backend, csic_frame_graph **out)
 {
     if (!out) return set_error(CSIC_EINVAL_NULL, "out is NULL");
     *out = nullptr;
     if (!plan || !d_in || !d_out) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
     if (nframes < 1 || nframes > 65536) return set_error(CSIC_EINVAL_SIZE, "nframes must be in 1..65536. Got %d", nframes);
-    if (branches <= 0) branches = CSIC_FRAME_GRAPH_DEFAULT_BRANCHES;
+    if (backend != CSIC_FRAME_GRAPH_HIP && backend != CSIC_FRAME_GRAPH_DIRECT)
+        return set_error(CSIC_EINVAL_SIZE, "unknown frame-graph backend %d", backend);
+    const int cap = backend == CSIC_FRAME_GRAPH_DIRECT ? MAX_QUEUES : 16;
+    if (branches <= 0) {
+        // Defaults from profiles/r02_small_launch.md, by the frame's data-movement floor at 8 TB/s: overlap pays the
+        // more the smaller the launch; more than 4 queues/streams oversubscribe the 4 hardware queues.
+        //   DIRECT  8192x8192 (25 us): 1 queue 31.3 us, 2 queues 32.1;  8192x2048 (6.3 us): 8.31 / 7.88 / 8.21 us with
+        //           1 / 2 / 4;  8192x1024 (3.1 us): 4.69 / 3.87 / 3.99;  4K sf=4 (1.3 us): 2.78 / 2.12 / 1.68
+        //   HIP     8192x4096: 17.1 / 15.9 us with 1 / 2 chains;  8192x1024: 5.88 / 5.15 / 4.84 with 1 / 2 / 4;  4K sf=4: 3.67 / 3.40 / 2.98
+        const double floor_us = (double)plan_algorithmic_bytes(plan) / 8.0e6;
+        if (backend == CSIC_FRAME_GRAPH_DIRECT) branches = floor_us >= 10.0 ? 1 : floor_us >= 2.5 ? 2 : CSIC_FRAME_GRAPH_DEFAULT_QUEUES;
+        else                                    branches = floor_us >= 5.0 ? 2 : CSIC_FRAME_GRAPH_DEFAULT_BRANCHES;
+    }
+    if (branches > cap) branches = cap;
     if (branches > nframes) branches = nframes;
+    for (int k = 0; k < nframes; ++k)
+        if (!d_in[k] || !d_out[k]) return set_error(CSIC_EINVAL_NULL, "frame %d: device buffer is NULL", k);
     CSIC_DEVICE_SCOPE(plan_device(plan));
 
     csic_frame_graph *g = new (std::nothrow) csic_frame_graph();
     if (!g) return set_error(CSIC_ENOMEM, "out of host memory");
     g->device = plan_device(plan);
+    g->backend = backend;
     g->nframes = nframes;
     g->branches = branches;
-    std::vector<hipGraphNode_t> nodes;
-    try { nodes.resize(nframes); } catch (const std::bad_alloc &) { graph_free(g); return set_error(CSIC_ENOMEM, "out of host memory"); }
-
-    hipError_t e = hipGraphCreate(&g->graph, 0);
-    int st = CSIC_OK;
-    for (int k = 0; k < nframes && e == hipSuccess; ++k) {
-        LaunchDesc d;
-        st = prepare_launch(plan, d_in[k], d_out[k], 1, 0, 0, &d);
-        if (st != CSIC_OK) break;
-        void *params[1] = {&d.args};                       // copied by hipGraphAddKernelNode
-        hipKernelNodeParams np;
-        np.func = reinterpret_cast<void *>(d.fn);
-        np.gridDim = d.grid;
-        np.blockDim = d.block;
-        np.sharedMemBytes = 0;
-        np.kernelParams = params;
-        np.extra = nullptr;
-        const hipGraphNode_t *dep = (k >= branches) ? &nodes[k - branches] : nullptr;
-        e = hipGraphAddKernelNode(&nodes[k], g->graph, dep, dep ? 1 : 0, &np);
-    }
-    if (st == CSIC_OK && e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    const int st = backend == CSIC_FRAME_GRAPH_DIRECT ? build_direct(g, plan, d_in, d_out) : build_hip(g, plan, d_in, d_out);
     if (st != CSIC_OK) { graph_free(g); return st; }
-    if (e != hipSuccess) {
-        graph_free(g);
-        return set_error(CSIC_EHIP, "building the frame graph failed: %s", hipGetErrorString(e));
-    }
     *out = g;
     clear_error();
     return CSIC_OK;
+}
+
+int csic_frame_graph_create(csic_plan *plan, const void *const *d_in, void *const *d_out, int32_t nframes,
+                            int32_t branches, csic_frame_graph **out)
+{
+    return csic_frame_graph_create_ex(plan, d_in, d_out, nframes, branches, CSIC_FRAME_GRAPH_HIP, out);
 }
 
 int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
 {
     if (!g) return set_error(CSIC_EINVAL_NULL, "graph is NULL");
     CSIC_DEVICE_SCOPE(g->device);
-    HIP_TRY(hipGraphLaunch(g->exec, static_cast<hipStream_t>(hip_stream)));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (g->backend == CSIC_FRAME_GRAPH_DIRECT) {
+        // the library's queues are not HIP streams: order by the host (see csic.h)
+        HIP_TRY(hipStreamSynchronize(stream));
+        int64_t t = 0;
+        int st = direct_submit(g, &t);
+        if (st == CSIC_OK) st = direct_wait(g, t);
+        if (st == CSIC_OK) clear_error();
+        return st;
+    }
+    const int B = g->branches;
+    if (B > 1) {
+        HIP_TRY(hipEventRecord(g->fork, stream));
+        for (int i = 1; i < B; ++i) HIP_TRY(hipStreamWaitEvent(g->streams[i], g->fork, 0));
+    }
+    for (int i = 0; i < B; ++i) HIP_TRY(hipGraphLaunch(g->execs[i], i == 0 ? stream : g->streams[i]));
+    for (int i = 1; i < B; ++i) {
+        HIP_TRY(hipEventRecord(g->joins[i], g->streams[i]));
+        HIP_TRY(hipStreamWaitEvent(stream, g->joins[i], 0));
+    }
     clear_error();
     return CSIC_OK;
+}
+
+int csic_frame_graph_submit(csic_frame_graph *g, int64_t *ticket)
+{
+    if (!g) return set_error(CSIC_EINVAL_NULL, "graph is NULL");
+    if (g->backend != CSIC_FRAME_GRAPH_DIRECT)
+        return set_error(CSIC_EINVAL_SIZE, "csic_frame_graph_submit needs a CSIC_FRAME_GRAPH_DIRECT graph (use csic_frame_graph_launch)");
+    CSIC_DEVICE_SCOPE(g->device);
+    const int st = direct_submit(g, ticket);
+    if (st == CSIC_OK) clear_error();
+    return st;
+}
+
+int csic_frame_graph_wait(csic_frame_graph *g, int64_t ticket)
+{
+    if (!g) return set_error(CSIC_EINVAL_NULL, "graph is NULL");
+    if (g->backend != CSIC_FRAME_GRAPH_DIRECT)
+        return set_error(CSIC_EINVAL_SIZE, "csic_frame_graph_wait needs a CSIC_FRAME_GRAPH_DIRECT graph (synchronize the stream instead)");
+    if (g->next_ticket == 0) { clear_error(); return CSIC_OK; }
+    const int st = direct_wait(g, ticket);
+    if (st == CSIC_OK) clear_error();
+    return st;
 }
 
 int csic_frame_graph_count(const csic_frame_graph *g, int32_t *nframes, int32_t *branches)
@@ -94,10 +595,17 @@ int csic_frame_graph_count(const csic_frame_graph *g, int32_t *nframes, int32_t 
     return CSIC_OK;
 }
 
+int csic_frame_graph_backend(const csic_frame_graph *g)
+{
+    if (!g) return set_error(CSIC_EINVAL_NULL, "graph is NULL");
+    return g->backend;
+}
+
 int csic_frame_graph_destroy(csic_frame_graph *g)
 {
     if (!g) return CSIC_OK;
     DeviceGuard guard(g->device);
+    if (g->backend == CSIC_FRAME_GRAPH_DIRECT && g->eng && g->next_ticket > g->waited) (void)direct_wait(g, -1);
     graph_free(g);
     return CSIC_OK;
 }

@@ -62,5 +62,6 @@ int enqueue(const LaunchDesc &d, hipStream_t stream);
 int launch_on_stream(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream);
 int plan_device(const csic_plan *pl);
 void plan_sizes(const csic_plan *pl, size_t *in_px, size_t *out_px);
+int64_t plan_algorithmic_bytes(const csic_plan *pl);          // per frame (csic_algorithmic_bytes of the plan's parameters)
 
 } // namespace csic

@@ -904,6 +904,11 @@ int launch_on_stream(csic_plan *pl, const void *d_in, void *d_out, int nframes, 
     return launch(pl, d_in, d_out, nframes, stream);
 }
 int plan_device(const csic_plan *pl) { return pl->device; }
+int64_t plan_algorithmic_bytes(const csic_plan *pl)
+{
+    int64_t b = 0;
+    return csic_algorithmic_bytes(&pl->p, &b) == CSIC_OK ? b : 0;
+}
 void plan_sizes(const csic_plan *pl, size_t *in_px, size_t *out_px)
 {
     *in_px = (size_t)pl->g.W * pl->g.H;

@@ -100,8 +100,10 @@ class StripedImageCompressorTop:
 
     def _exchange_halo(self, local_rows):
         """One neighbour exchange: my trailing `tail_below` rows go to rank+1, `halo_above` rows arrive from
-        rank-1 (isend/irecv pairs: NCCL send/recv over xGMI on GPUs, gloo in the CPU tests).  Returns the
-        aligned range [proc_row0, proc_row0 + proc_nrows) this rank processes."""
+        rank-1 (isend/irecv pairs).  With backend "nccl" (RCCL) CUDA rows travel GPU to GPU over xGMI; gloo has
+        no GPU send/recv, so there (CPU tests, and rehearsals where several ranks share one GPU) CUDA rows are
+        staged through host memory -- a few rows, only on that backend.  Returns the aligned range
+        [proc_row0, proc_row0 + proc_nrows) this rank processes."""
         import numpy as np
         import torch
         dist, st = self._dist, self.stripe
@@ -109,18 +111,20 @@ class StripedImageCompressorTop:
         is_np = not hasattr(local_rows, "is_cuda")
         t = torch.from_numpy(np.ascontiguousarray(local_rows).view(np.int32).reshape(-1, W)) if is_np \
             else local_rows.reshape(-1, W)
+        stage = t.is_cuda and dist.get_backend(self.group) != "nccl"
+        wire = torch.device("cpu") if stage else t.device
         ops, halo = [], None
         if st.tail_below > 0:
-            tail = t[st.nrows - st.tail_below:].contiguous()
+            tail = t[st.nrows - st.tail_below:].contiguous().to(wire)
             ops.append(dist.P2POp(dist.isend, tail, self._global_rank(self.rank + 1), self.group))
         if st.halo_above > 0:
-            halo = torch.empty((st.halo_above, W), dtype=t.dtype, device=t.device)
+            halo = torch.empty((st.halo_above, W), dtype=t.dtype, device=wire)
             ops.append(dist.P2POp(dist.irecv, halo, self._global_rank(self.rank - 1), self.group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         body = t[: st.nrows - st.tail_below]
-        ext = body if halo is None else torch.cat([halo, body], 0)
+        ext = body if halo is None else torch.cat([halo.to(t.device), body], 0)
         return ext.numpy().view(np.uint32) if is_np else ext.contiguous()
 
     def _global_rank(self, group_rank: int) -> int:

@@ -223,27 +223,52 @@ int  csic_copy_device(void *d_dst, const void *d_src, int64_t npix, void *hip_st
  * (pixel, index) pairs), for the full-size parity properties; synchronous. */
 int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *hip_stream);
 
-/* ---- per-frame launches captured in one hipGraph (BASELINE.json configs[4], "hipGraph-captured per-frame
- * launch") ---------------------------------------------------------------------------------------------
+/* ---- pre-recorded per-frame launches (BASELINE.json configs[4], "hipGraph-captured per-frame launch") ------
  * A stream of frames that live in SEPARATE device buffers (a decoder's surface pool) cannot use the one
- * contiguous batched launch of csic_process_batch_device.  csic_frame_graph_create builds a hipGraph with one
- * kernel node per frame (frame k: d_in[k] -> d_out[k]; same preconditions as csic_process_device) and
- * instantiates it once; csic_frame_graph_launch replays it on `hip_stream`.  The reference processes images
- * strictly one after the other (ImageCompressorTopApp.scala:23-145, one DUT per image); frames are independent,
- * so the only ordering the graph keeps is what `branches` asks for:
- *   branches = 1 : a chain, frame k+1 after frame k -- what capturing a loop of csic_process_device calls on ONE
- *                  stream yields; every node pays the dependent-kernel boundary (~1.7 us on MI355X).
- *   branches = B : B independent chains (frame k depends on frame k-B), so up to B frame kernels are in flight
- *                  and one frame's launch ramp and drain overlap its neighbours' streaming.
- *   branches <= 0: the library's default (CSIC_FRAME_GRAPH_DEFAULT_BRANCHES).
- * All outputs are complete when work enqueued on `hip_stream` after the launch runs.  The pointer arrays are
- * read at creation only; the buffers they name must stay valid for as long as the graph is launched. */
-#define CSIC_FRAME_GRAPH_DEFAULT_BRANCHES 8
+ * contiguous batched launch of csic_process_batch_device, and a frame of 10-25 MB is only 1.3-3 us of HBM time
+ * behind the ~1.7 us dependent-kernel boundary that every launch on a HIP stream -- eager or replayed from a
+ * hipGraph chain -- pays.  A frame graph records one launch per frame once (frame k: d_in[k] -> d_out[k]; same
+ * preconditions as csic_process_device) and replays them so that independent frames overlap.  The reference
+ * processes images strictly one after the other (ImageCompressorTopApp.scala:23-145, a fresh DUT per image);
+ * frames are independent, so no ordering between them has to be kept.  Two backends:
+ *
+ *   CSIC_FRAME_GRAPH_HIP     `branches` hipGraph chains (kernel nodes identical to the eager launch), chain 0
+ *                            replayed on the caller's stream, the others on internal streams forked from and
+ *                            joined to it by events: csic_frame_graph_launch is asynchronous and fully ordered
+ *                            with `hip_stream`.  branches = 1 is the strictly serial graph that capturing a loop
+ *                            of csic_process_device calls gives.  (ONE hipGraph with parallel branches is not
+ *                            used: ROCm 7.2 replays such a graph node by node from the host, slower than a chain.)
+ *   CSIC_FRAME_GRAPH_DIRECT  the same launches as pre-built AQL kernel-dispatch packets on `branches` (= queues,
+ *                            default 4, max 8) user-mode HSA queues owned by the library, frame k on queue
+ *                            k % queues, WITHOUT the barrier bit HIP sets on every packet: consecutive frames
+ *                            overlap like the workgroups of one big launch (cfg 5 frame: 3.65 us in a hipGraph
+ *                            chain, 1.76 us here, 1.75 us in one batched launch).  These queues are NOT HIP
+ *                            streams: csic_frame_graph_submit starts the work immediately -- the caller makes
+ *                            the inputs ready first (e.g. by synchronising the producing stream) -- and returns
+ *                            a ticket; csic_frame_graph_wait blocks the host until that submission (and all
+ *                            earlier ones of this graph) has finished, outputs visible to host and device.  Up to
+ *                            16 submissions may be outstanding per graph (a 17th waits for the oldest); they are
+ *                            not ordered among themselves.  csic_frame_graph_launch on a DIRECT graph is the
+ *                            synchronous composition  hipStreamSynchronize(hip_stream) + submit + wait.
+ *
+ * branches <= 0 selects the backend's default for the frame size (more overlap for smaller frames; measured table
+ * in profiles/r02_small_launch.md).  The pointer arrays are read at creation only; the buffers they
+ * name must stay valid for as long as the graph is launched.  csic_frame_graph_create == _create_ex with
+ * CSIC_FRAME_GRAPH_HIP. */
+#define CSIC_FRAME_GRAPH_HIP    0
+#define CSIC_FRAME_GRAPH_DIRECT 1
+#define CSIC_FRAME_GRAPH_DEFAULT_BRANCHES 4   /* HIP backend, small frames (2 chains when a frame is >= 5 us of HBM time)          */
+#define CSIC_FRAME_GRAPH_DEFAULT_QUEUES   4   /* DIRECT backend, small frames (2 queues from 2.5 us, 1 queue from 10 us per frame) */
 typedef struct csic_frame_graph csic_frame_graph;
 int  csic_frame_graph_create(csic_plan *plan, const void *const *d_in, void *const *d_out, int32_t nframes,
                              int32_t branches, csic_frame_graph **out);
+int  csic_frame_graph_create_ex(csic_plan *plan, const void *const *d_in, void *const *d_out, int32_t nframes,
+                                int32_t branches, int32_t backend, csic_frame_graph **out);
 int  csic_frame_graph_launch(csic_frame_graph *graph, void *hip_stream);
+int  csic_frame_graph_submit(csic_frame_graph *graph, int64_t *ticket);            /* DIRECT only */
+int  csic_frame_graph_wait(csic_frame_graph *graph, int64_t ticket);               /* DIRECT only; ticket < 0 = all */
 int  csic_frame_graph_count(const csic_frame_graph *graph, int32_t *nframes, int32_t *branches);
+int  csic_frame_graph_backend(const csic_frame_graph *graph);                      /* CSIC_FRAME_GRAPH_* or < 0 */
 int  csic_frame_graph_destroy(csic_frame_graph *graph);
 
 /* ---- PNG files (host only, zlib) --------------------------------------------------------------------

@@ -44,3 +44,41 @@ def test_bench_fails_loudly_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no CPU fallback" in (r.stdout + r.stderr)
+
+
+def test_traffic_lookup_is_keyed_on_the_kernel_sources(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed PMC pass; it must turn into null (with the reason) as soon as the
+    kernel sources or the selected kernel differ from what was profiled."""
+    bench = _load_bench()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from srchash import kernel_source_sha256
+    have = kernel_source_sha256(ROOT)
+    assert len(have) == 64 and have == kernel_source_sha256(ROOT)
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    ent = {"cfg4": {"plan_kernel": "k_x", "tag": "t", "hbm_bytes_per_launch": 123, "note": "n", "source_sha256": have}}
+    (prof / "pmc_traffic.json").write_text(json.dumps(ent))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    import srchash
+    monkeypatch.setattr(srchash, "kernel_source_sha256", lambda root=ROOT: have)
+    assert bench.load_traffic("cfg4", "k_x", 1)[0] == 123
+    t, why = bench.load_traffic("cfg4", "k_other", 1)
+    assert t is None and "stale" in why
+    t, why = bench.load_traffic("cfg5", "k_x", 1)
+    assert t is None and "no PMC entry" in why
+    assert bench.load_traffic("cfg4", "k_x", 2)[0] is None
+    ent["cfg4"]["source_sha256"] = "0" * 64
+    (prof / "pmc_traffic.json").write_text(json.dumps(ent))
+    t, why = bench.load_traffic("cfg4", "k_x", 1)
+    assert t is None and "stale" in why and "re-run" in why
+
+
+def test_committed_traffic_entries_carry_a_source_hash():
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    for name, ent in json.load(open(path)).items():
+        assert len(ent.get("source_sha256", "")) == 64, name
+
+
+def test_strong_scaling_is_the_default_for_n_gt_1():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'ap.add_argument("--scaling", default="strong"' in src

@@ -26,8 +26,9 @@ def _oparams(orc, W, H, a, b, bits, f, op=CSQ, rounding=0):
                             cr_bits=bits[2], factor=f, op=op, rounding=rounding)
 
 
+@pytest.mark.parametrize("backend", ["hip", "direct"])
 @pytest.mark.parametrize("branches", [1, 2, 3, None, 64])
-def test_frame_graph_small_frames(csic, oracle, branches):
+def test_frame_graph_small_frames(csic, oracle, branches, backend):
     """7 frames in SEPARATE allocations (not one contiguous batch), every chain layout."""
     import torch
     W, H, n = 200, 36, 7
@@ -36,7 +37,7 @@ def test_frame_graph_small_frames(csic, oracle, branches):
     with csic.Plan(cp, 0) as pl:
         d_ins = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
         d_outs = [torch.zeros(pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0") for _ in range(n)]
-        with csic.FrameGraph(pl, d_ins, d_outs, branches=branches) as g:
+        with csic.FrameGraph(pl, d_ins, d_outs, branches=branches, backend=backend) as g:
             assert g.nframes == n and 1 <= g.branches <= n
             for rep in range(3):                                       # a graph is replayable
                 for t in d_outs:
@@ -48,7 +49,8 @@ def test_frame_graph_small_frames(csic, oracle, branches):
                     assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(want.shape), want), (rep, k)
 
 
-def test_frame_graph_every_kernel_family(csic, oracle):
+@pytest.mark.parametrize("backend", ["hip", "direct"])
+def test_frame_graph_every_kernel_family(csic, oracle, backend):
     """f = 1 vector kernel, k_dec in both order classes, k_generic and the AVG extension through graph nodes."""
     import torch
     n = 3
@@ -60,7 +62,7 @@ def test_frame_graph_every_kernel_family(csic, oracle):
         with csic.Plan(cp, 0) as pl:
             d_ins = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
             d_outs = [torch.zeros(pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0") for _ in range(n)]
-            with csic.FrameGraph(pl, d_ins, d_outs, branches=2) as g:
+            with csic.FrameGraph(pl, d_ins, d_outs, branches=2, backend=backend) as g:
                 g.launch()
                 torch.cuda.synchronize()
             for k in range(n):
@@ -89,6 +91,65 @@ def test_frame_graph_errors(csic):
         assert N.lib().csic_frame_graph_destroy(None) == 0
 
 
+def test_direct_graph_many_outstanding_submissions(csic, oracle):
+    """DIRECT backend: submit() returns at once; more submissions than the 16 slots recycle the oldest; wait(-1)
+    drains everything.  Unaligned frame pointers make some nodes fall back to the 4-byte kernels (a second kernel
+    object in the same graph)."""
+    import torch
+    W, H, n = 256, 32, 9
+    cp = csic.make_c_params(W, H, 2, 2, 4, 4, 4, 1, CSQ)
+    host = [oracle.synth_frame(W * H, 77 + k) for k in range(n)]
+    with csic.Plan(cp, 0) as pl:
+        pool = torch.zeros(n * (W * H + 1), dtype=torch.int32, device="cuda:0")
+        d_ins = []
+        for k, h in enumerate(host):                                    # odd frames start 4 bytes off a 16-byte boundary
+            off = k * (W * H + 1) + (k & 1)
+            d_ins.append(pool[off:off + W * H])
+            d_ins[-1].copy_(torch.from_numpy(h.view(np.int32)))
+        d_outs = [torch.zeros(W * H, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+        torch.cuda.synchronize()
+        with csic.FrameGraph(pl, d_ins, d_outs, backend="direct") as g:
+            assert g.branches == csic._native.FRAME_GRAPH_DEFAULT_QUEUES          # 256x32 frames: far below 2.5 us
+            tickets = [g.submit() for _ in range(40)]
+            assert tickets == list(range(40))
+            g.wait(tickets[10])
+            g.wait()
+            g.wait()                                                     # idempotent
+            with pytest.raises(csic.IllegalArgumentException):
+                csic._native.check(csic._native.lib().csic_frame_graph_submit(None, None))
+        want = [oracle.process(_oparams(oracle, W, H, 2, 2, (4, 4, 4), 1), h, form="closed") for h in host]
+        for k in range(n):
+            assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(H, W), want[k]), k
+        # submit/wait are DIRECT-only
+        with csic.FrameGraph(pl, d_ins, d_outs, backend="hip") as g:
+            with pytest.raises(csic.IllegalArgumentException):
+                g.submit()
+
+
+def test_direct_graph_larger_than_the_queue_rings(csic, oracle):
+    """5000 tiny frames on ONE queue exceed the 4096-packet ring: the submission flows through it in chunks."""
+    import torch
+    W, H, n = 16, 8, 5000
+    cp = csic.make_c_params(W, H, 2, 0, 8, 8, 8, 2, CSQ)
+    host = oracle.synth_frame(n * W * H, 5)
+    with csic.Plan(cp, 0) as pl:
+        opx = pl.out_width * pl.out_height
+        d_in = torch.from_numpy(host.view(np.int32)).cuda()
+        d_out = torch.zeros(n * opx, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        with csic.FrameGraph(pl, [d_in[k * W * H:(k + 1) * W * H] for k in range(n)],
+                             [d_out[k * opx:(k + 1) * opx] for k in range(n)], branches=1, backend="direct") as g:
+            g.wait(g.submit())
+        got = d_out.cpu().numpy().view(np.uint32).reshape(n, opx)
+        for k in range(0, n, 97):
+            want = oracle.process(_oparams(oracle, W, H, 2, 0, (8, 8, 8), 2), host[k * W * H:(k + 1) * W * H], form="closed")
+            assert np.array_equal(got[k], want.reshape(-1)), k
+        ref = torch.zeros_like(d_out)
+        pl.process_device(d_in, ref, nframes=n)
+        torch.cuda.synchronize()
+        assert torch.equal(ref, d_out)
+
+
 def test_entry_points_leave_the_callers_device_current(csic):
     """a csic_* call on a plan must not change the calling thread's current HIP device.  On a 1-GPU box
     the observable part is that the device is still 0 and no sticky error is left behind."""
@@ -105,8 +166,9 @@ def test_entry_points_leave_the_callers_device_current(csic):
 
 def test_cfg5_literal_64_frames_graph_and_batched(csic, oracle):
     """BASELINE.json configs[4] at full size: 64 x 3840x2160 ARGB (2.1 GB, generated on the device), 4:2:0, sf=4,
-    bits 3/3/2.  (1) one hipGraph of 64 per-frame launches in a single chain, (2) the same with 8 chains,
-    (3) one batched launch; all 64 x 3 outputs against orc_process_closed_mt on host copies of the frames."""
+    bits 3/3/2.  (1) one hipGraph of 64 per-frame launches in a single chain, (2) three hipGraph chains on three
+    streams, (3) the direct AQL backend on four queues, (4) one batched launch; all 64 x 4 outputs against
+    orc_process_closed_mt on host copies of the frames."""
     import torch
     W, H, n = 3840, 2160, 64
     N = csic._native
@@ -119,10 +181,12 @@ def test_cfg5_literal_64_frames_graph_and_batched(csic, oracle):
         d_in = torch.empty(n * ipx, dtype=torch.int32, device="cuda:0")
         sh = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         N.check(lib.csic_synth_frame_device(C.c_void_p(d_in.data_ptr()), d_in.numel(), 0, 20250629, sh))
-        outs = {name: torch.zeros(n * opx, dtype=torch.int32, device="cuda:0") for name in ("chain", "forked", "batched")}
+        outs = {name: torch.zeros(n * opx, dtype=torch.int32, device="cuda:0") for name in ("chain", "forked", "direct", "batched")}
         frames_in = [d_in[k * ipx:(k + 1) * ipx] for k in range(n)]
-        for name, br in (("chain", 1), ("forked", 8)):
-            with csic.FrameGraph(pl, frames_in, [outs[name][k * opx:(k + 1) * opx] for k in range(n)], branches=br) as g:
+        torch.cuda.synchronize()
+        for name, br, backend in (("chain", 1, "hip"), ("forked", 3, "hip"), ("direct", 4, "direct")):
+            with csic.FrameGraph(pl, frames_in, [outs[name][k * opx:(k + 1) * opx] for k in range(n)], branches=br,
+                                 backend=backend) as g:
                 assert (g.nframes, g.branches) == (n, br)
                 g.launch()
                 torch.cuda.synchronize()
@@ -135,3 +199,19 @@ def test_cfg5_literal_64_frames_graph_and_batched(csic, oracle):
             want = oracle.process_mt(op, host_frame, nthreads).reshape(-1)
             for name in got:
                 assert np.array_equal(got[name][k], want), (name, k)
+
+
+def test_two_ranks_sharing_the_gpu_halo_exchange_with_cuda_rows():
+    """StripedImageCompressorTop with the real HIP Plan, CUDA-tensor rows and unaligned `row_splits`,
+    two gloo ranks sharing device 0, against the oracle -- tools/rehearse_multi.py under the same launcher the
+    driver uses for N > 1 (a child process: the launcher starts before anything there touches the GPU)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29531", os.path.join(ROOT, "tools", "rehearse_multi.py"), "halo"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert '"all_bit_exact": true' in r.stdout
+    assert r.stdout.count('"case": "halo"') == 10 and '"bit_exact_all_ranks": false' not in r.stdout

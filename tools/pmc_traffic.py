@@ -15,6 +15,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from srchash import kernel_source_sha256  # noqa: E402
 
 
 def counter_means(d, counter):
@@ -78,6 +80,9 @@ def main():
         wr = v["WRITE_SIZE_mean"] * 1024 * 1.0
         traffic[config] = {
             "plan_kernel": plan_kernel, "rocprof_kernel": k, "tag": tag,
+            # the counters describe exactly these sources (the .so that was profiled travels with them to the GPU
+            # box); bench.py reports the traffic only while the checkout still hashes to this value
+            "source_sha256": kernel_source_sha256(ROOT),
             "hbm_read_bytes_per_launch": round(rd), "hbm_write_bytes_per_launch": round(wr),
             "hbm_bytes_per_launch": round(rd + wr),
             "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB units); read side x2 per "

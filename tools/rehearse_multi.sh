@@ -1,0 +1,22 @@
+#!/bin/bash
+# tools/rehearse_multi.sh [TAG] -- on the 1-GPU box: the N > 1 launcher path, twice, two ranks sharing GPU 0
+# over gloo.  Logs: gpurun_out/<TAG>_multi_rehearsal.{halo,bench}.log (copied to profiles/).
+#   (a) StripedImageCompressorTop, real HIP Plan, CUDA rows, aligned stripes + unaligned row_splits (_exchange_halo)
+#   (b) bench.py --gpus 2 --backend gloo: strong split of ONE 8192x8192 frame as `value`, weak beside it
+set -o pipefail
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+cd "$ROOT"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+    tools/rehearse_multi.py halo > "$OUT/${TAG}_multi_rehearsal.halo.log" 2>&1
+rc=$?
+tail -n 4 "$OUT/${TAG}_multi_rehearsal.halo.log"
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 \
+    bench.py --gpus 2 --backend gloo --steps 1000 --warmup 200 > "$OUT/${TAG}_multi_rehearsal.bench.log" 2>&1
+rc=$?
+tail -n 2 "$OUT/${TAG}_multi_rehearsal.bench.log"
+exit $rc

@@ -34,8 +34,9 @@ def main():
     ap.add_argument("--what", default="stripes,cfg5,cfg23")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "small_launch.jsonl"))
     ap.add_argument("--reps", type=int, default=30)
-    ap.add_argument("--branches", default="1,2,3,4,8,16")
+    ap.add_argument("--branches", default="1,2,3,4,6,8")
     ap.add_argument("--threads", default="256,128,64")
+    ap.add_argument("--backends", default="hip,direct")
     args = ap.parse_args()
 
     import torch
@@ -55,7 +56,22 @@ def main():
         fout.write(line + "\n")
         fout.flush()
 
+    import time
+
     def time_graph(g, nlaunch, reps):
+        if g.backend == "direct":
+            # the library's own queues: no HIP events there; host wall clock over `reps` submissions kept in flight
+            g.wait(g.submit())
+            best, tot = 1e9, 0.0
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    g.submit()
+                g.wait()
+                us = (time.perf_counter() - t0) * 1e6 / reps
+                best = min(best, us)
+                tot += us
+            return tot / 3 / nlaunch, best / nlaunch
         for _ in range(5):
             g.launch()
         torch.cuda.synchronize()
@@ -72,12 +88,16 @@ def main():
         return tot / reps * 1e3 / nlaunch, best * 1e3 / nlaunch        # us per launch (avg, best)
 
     def prewarm(g, ms=300.0):
-        import time
         t_end = time.perf_counter() + ms * 1e-3
         while time.perf_counter() < t_end:
-            for _ in range(8):
-                g.launch()
-            torch.cuda.synchronize()
+            if g.backend == "direct":
+                for _ in range(8):
+                    g.submit()
+                g.wait()
+            else:
+                for _ in range(8):
+                    g.launch()
+                torch.cuda.synchronize()
 
     def run_case(tag, W, H, a, b, bits, f, nframes_ring, nodes, branches_list, threads_list, fpl=1):
         """fpl = frames per launch (contiguous batch inside one node) -- for cfg2/cfg3 style tiny frames."""
@@ -93,14 +113,16 @@ def main():
         d_ins = [ins[(k % nframes_ring) * in_px:(k % nframes_ring + 1) * in_px] for k in range(nodes)]
         d_outs = [outs[(k % nframes_ring) * out_px:(k % nframes_ring + 1) * out_px] for k in range(nodes)]
         for thr in threads_list:
-            plan.tune(N.TUNE_BLOCK_THREADS, thr)
+          plan.tune(N.TUNE_BLOCK_THREADS, thr)
+          for backend in args.backends.split(","):
             for br in branches_list:
-                if br > nodes:
+                if br > nodes or (backend == "direct" and br > 8) or (backend == "hip" and br > 16):
                     continue
-                g = csic.FrameGraph(plan, d_ins, d_outs, branches=br)
+                g = csic.FrameGraph(plan, d_ins, d_outs, branches=br, backend=backend)
                 prewarm(g)
                 avg, best = time_graph(g, nodes, args.reps)
                 emit({"case": tag, "shape": f"{W}x{H}", "f": f, "chroma": f"4:{a}:{b}", "kernel": plan.kernel_name,
+                      "backend": backend, "timing": "host wall clock, submissions in flight" if backend == "direct" else "HIP events per replay",
                       "block_threads": thr, "branches": br, "nodes": nodes, "ring_frames": nframes_ring,
                       "us_per_launch": round(avg, 3), "us_per_launch_best": round(best, 3),
                       "alg_bytes": alg, "floor_us": round(floor_us, 3), "frac_of_8TBs": round(floor_us / avg, 4)})
@@ -134,7 +156,7 @@ def main():
         for Hs, ring in ((8192, 8), (4096, 16), (2048, 32), (1024, 64), (512, 64)):
             run_case(f"cfg4 stripe 1/{8192 // Hs}", 8192, Hs, 2, 0, (8, 8, 8), 2, ring, 64, brs, thr if Hs <= 2048 else [256])
     if "cfg5" in what:
-        run_case("cfg5 frame", 3840, 2160, 2, 0, (3, 3, 2), 4, 64, 64, brs + [64], thr)
+        run_case("cfg5 frame", 3840, 2160, 2, 0, (3, 3, 2), 4, 64, 64, brs, thr)
     if "cfg23" in what:
         run_case("cfg3 frame", 512, 512, 2, 0, (3, 3, 2), 2, 1024, 256, brs, [256])
         run_case("cfg2 frame", 128, 128, 2, 2, (3, 3, 2), 1, 4096, 256, brs, [256])

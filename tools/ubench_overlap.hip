@@ -150,6 +150,33 @@ int main(int argc, char **argv)
         char nm[32]; snprintf(nm, sizeof nm, "graph-b%d", B);
         replay(nm, g);
     }
+    // S chain graphs (each on the fast pre-built-packet path) replayed concurrently on S streams, fork/join by events
+    for (int S : {2, 3, 4, 6, 8}) {
+        std::vector<hipGraphExec_t> ex(S);
+        std::vector<hipGraph_t> gs(S);
+        for (int i = 0; i < S; ++i) {
+            CK(hipGraphCreate(&gs[i], 0));
+            hipGraphNode_t prev{};
+            bool have = false;
+            for (int k = i; k < N; k += S) {
+                void *params[1] = {&d[k].args};
+                hipKernelNodeParams np{};
+                np.func = (void *)d[k].fn; np.gridDim = d[k].grid; np.blockDim = d[k].block; np.kernelParams = params;
+                hipGraphNode_t node;
+                CK(hipGraphAddKernelNode(&node, gs[i], have ? &prev : nullptr, have ? 1 : 0, &np));
+                prev = node; have = true;
+            }
+            CK(hipGraphInstantiate(&ex[i], gs[i], nullptr, nullptr, 0));
+        }
+        char nm[32]; snprintf(nm, sizeof nm, "mchain%d", S);
+        report(nm, [&] {
+            CK(hipEventRecord(fork, s[0]));
+            for (int i = 1; i < S; ++i) CK(hipStreamWaitEvent(s[i], fork, 0));
+            for (int i = 0; i < S; ++i) CK(hipGraphLaunch(ex[i], s[i]));
+            for (int i = 1; i < S; ++i) { CK(hipEventRecord(join[i], s[i])); CK(hipStreamWaitEvent(s[0], join[i], 0)); }
+        });
+        for (int i = 0; i < S; ++i) { CK(hipGraphExecDestroy(ex[i])); CK(hipGraphDestroy(gs[i])); }
+    }
     // one batched launch of the same 64 frames (contiguous): the bound overlap can approach
     {
         LaunchDesc b;
