@@ -43,6 +43,9 @@ CONFIGS = {
     "cfg5": (3840, 2160, 2, 0, (3, 3, 2), 4, 64),
     "8k_444_f1": (8192, 8192, 4, 4, (8, 8, 8), 1, 1),
     "8k_420_f1": (8192, 8192, 2, 0, (3, 3, 2), 1, 1),
+    # with --order scq: spatial before chroma where f does not divide W -> k_generic; sq1024 is the nearest fast-path shape
+    "sq1000": (1000, 1000, 2, 0, (8, 8, 8), 8, 1),
+    "sq1024": (1024, 1024, 2, 0, (8, 8, 8), 8, 1),
 }
 # AVG sampling extension (no reference counterpart): same shapes as cfg4 / cfg5, every input row is live
 AVG_CONFIGS = {"avg_8k_420_sf2": "cfg4", "avg_4k_420_sf4": "cfg5"}
@@ -423,7 +426,11 @@ def main(argv=None):
                          "stripe size, 1 = single-stream order)")
     ap.add_argument("--direct-queues", type=int, default=0,
                     help="queues of the direct-dispatch side measurement (0 = library default for the frame size)")
-    ap.add_argument("--no-direct", action="store_true", help="skip the direct-dispatch side measurement")
+    ap.add_argument("--direct", action="store_true",
+                    help="N=1: also time the same K steps through the direct-dispatch engine and report them beside the "
+                         "headline (default at N>1; off by default at N=1 so that `rocprofv3 --stats` of the default command "
+                         "sees only the serial HIP-stream launches the roofline is measured on)")
+    ap.add_argument("--no-direct", action="store_true", help="N>1: skip the direct-dispatch side measurement")
     ap.add_argument("--streams", type=int, default=1,
                     help="EXPERIMENT (default 1 = the contract): issue consecutive steps round-robin on this many HIP "
                          "streams so that one frame's ramp-up overlaps the previous frame's drain.  Per-kernel durations "
@@ -508,7 +515,8 @@ def main(argv=None):
 
     # ---- the same K steps through the direct-dispatch engine (side measurement, every N) ---------------
     direct = None
-    if not args.no_direct and args.streams <= 1 and (wl.fps == 1 or wl.per_frame_graph):
+    want_direct = args.direct or (world > 1 and not args.no_direct)
+    if want_direct and args.streams <= 1 and (wl.fps == 1 or wl.per_frame_graph):
         eld = timed_direct(wl, args, torch, dist, world, args.backend, dev)
         pxd = allsum(float(wl.in_px) * wl.fps * K)
         per_launch_ms = eld * 1e3 / K / wl.launches_per_step

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 REPLAYS = 12
 
 
-def run(threads, branches):
+def run(threads, branches, backend="hip"):
     import ctypes as C
     import torch
     import csic_amd as csic
@@ -31,12 +31,16 @@ def run(threads, branches):
     d_out = torch.empty(n * opx, dtype=torch.int32, device="cuda:0")
     sh = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     N.check(N.lib().csic_synth_frame_device(C.c_void_p(d_in.data_ptr()), d_in.numel(), 0, 20250629, sh))
-    g = csic.FrameGraph(plan, [d_in[k * ipx:(k + 1) * ipx] for k in range(n)],
-                        [d_out[k * opx:(k + 1) * opx] for k in range(n)], branches=branches)
-    for _ in range(REPLAYS):
-        g.launch()
     torch.cuda.synchronize()
-    print(json.dumps({"kernel": plan.kernel_name, "threads": threads, "branches": g.branches, "replays": REPLAYS}))
+    g = csic.FrameGraph(plan, [d_in[k * ipx:(k + 1) * ipx] for k in range(n)],
+                        [d_out[k * opx:(k + 1) * opx] for k in range(n)], branches=branches, backend=backend)
+    for _ in range(REPLAYS):
+        if backend == "direct":
+            g.wait(g.submit())
+        else:
+            g.launch()
+    torch.cuda.synchronize()
+    print(json.dumps({"kernel": plan.kernel_name, "threads": threads, "backend": backend, "branches": g.branches, "replays": REPLAYS}))
     g.close()
     plan.close()
 
@@ -72,6 +76,6 @@ def analyze(d):
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
-        run(int(sys.argv[2]), int(sys.argv[3]))
+        run(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "hip")
     else:
         analyze(sys.argv[2])

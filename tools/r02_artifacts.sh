@@ -1,0 +1,65 @@
+#!/bin/bash
+# tools/r02_artifacts.sh STAGE [TAG] -- regenerates the committed measurement artefacts of a round with the CURRENT
+# binary, on the GPU box (via gpurun); outputs under gpurun_out/<TAG>/, copied to profiles/ by tools/collect_artifacts.py.
+#   bench    : bench.py for every BASELINE config + extras -> bench_all_configs.jsonl
+#   profile  : rocprofv3 kernel-trace/stats + PMC passes for cfg4, cfg5, 8k_444_f1, 8k_420_f1 (tools/profile.sh)
+#   small    : tools/small_launch.py, tools/ubench_overlap, tools/ubench_aql, frame-graph kernel traces
+#   host     : tools/host_io.py
+#   sweep    : tools/sweep.py, tools/ubench
+set -o pipefail
+STAGE=${1:-bench}
+TAG=${2:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$ROOT"
+export TMPDIR=/tmp
+B="python bench.py --no-cpu-baseline --direct"
+case "$STAGE" in
+bench)
+  J=$OUT/bench_all_configs.jsonl; : > "$J"
+  python bench.py --cpu-budget 5 --direct >> "$J" 2> "$OUT/bench.err" || exit 1
+  for c in cfg5 8k_444_f1 8k_420_f1 avg_8k_420_sf2 avg_4k_420_sf4 cfg2 cfg3; do $B --config $c >> "$J" 2>> "$OUT/bench.err" || exit 1; done
+  $B --config cfg5 --per-frame-graph --graph-branches 1 --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  $B --config cfg5 --per-frame-graph --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  $B --config cfg2 --frames-per-step 4096 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  $B --config cfg3 --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  $B --config sq1000 --order scq --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  $B --config sq1024 --order scq --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  wc -l "$J"
+  ;;
+profile)
+  for c in cfg4 cfg5 8k_444_f1 8k_420_f1; do
+    bash tools/profile.sh $TAG $c > "$OUT/profile_$c.log" 2>&1 || { tail -5 "$OUT/profile_$c.log"; exit 1; }
+    echo "profiled $c"
+  done
+  ;;
+small)
+  rm -f "$OUT/small_launch.jsonl"
+  timeout -k 10 600 python tools/small_launch.py --threads 256,128 --out "$OUT/small_launch.jsonl" > "$OUT/small_launch.log" 2>&1 || exit 1
+  ( cd /tmp
+    timeout -k 10 150 $ROOT/tools/ubench_overlap cfg5 30 256 > "$OUT/ubench_overlap_cfg5.log" 2>&1 || exit 1
+    timeout -k 10 150 $ROOT/tools/ubench_overlap stripe8 30 256 > "$OUT/ubench_overlap_stripe8.log" 2>&1 || exit 1
+    timeout -k 10 150 $ROOT/tools/ubench_aql cfg5 20 256 > "$OUT/ubench_aql_cfg5.log" 2>&1 || exit 1
+    timeout -k 10 150 $ROOT/tools/ubench_aql stripe8 20 256 > "$OUT/ubench_aql_stripe8.log" 2>&1 || exit 1
+    : > "$OUT/cfg5_graph_trace_summary.jsonl"
+    for cfg in "hip 1" "hip 4" "direct 4"; do
+      set -- $cfg
+      d="$OUT/cfg5_graph_trace_$1_b$2"
+      rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -o trace -- python3 $ROOT/tools/graph_trace.py run 256 $2 $1 > "$d.log" 2>&1 || exit 1
+      python3 $ROOT/tools/graph_trace.py analyze "$d" >> "$OUT/cfg5_graph_trace_summary.jsonl" || exit 1
+    done ) || exit 1
+  cat "$OUT/cfg5_graph_trace_summary.jsonl"
+  ;;
+host)
+  timeout -k 10 900 python tools/host_io.py "$OUT/host_io.json" > "$OUT/host_io.log" 2>&1 || { tail -5 "$OUT/host_io.log"; exit 1; }
+  tail -40 "$OUT/host_io.log"
+  ;;
+sweep)
+  timeout -k 10 900 python tools/sweep.py > "$OUT/sweep.md" 2> "$OUT/sweep.err" || exit 1
+  tail -3 "$OUT/sweep.md"
+  ( cd /tmp && timeout -k 10 600 $ROOT/tools/ubench > "$OUT/ubench.log" 2>&1 ) || exit 1
+  tail -3 "$OUT/ubench.log"
+  ;;
+*) echo "unknown stage $STAGE"; exit 2 ;;
+esac

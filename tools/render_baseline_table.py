@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""tools/render_baseline_table.py [profiles/rNN_bench_all_configs.jsonl] -- renders the table of BASELINE.md section 3
+from the committed bench lines, so that every number quoted there is, by construction, a number in that file."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_bench_all_configs.jsonl")
+    print("| # | workload (`config.workload`) | launch (`config.launch`) | kernel | Mpx/s (input) | µs / step | algorithmic GB/s | % HBM roofline | direct dispatch: Mpx/s (µs / step, %) |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for i, l in enumerate(open(path), 1):
+        r = json.loads(l)
+        c, rf = r["config"], r["roofline"]
+        wl = c["workload"].replace(", FLOOR_HW", "").replace(" ARGB", "")
+        d = r.get("direct_dispatch")
+        dd = f"{d['value']:,.0f} ({1e3 * d['ms_per_step']:.2f}, {100 * d['roofline_frac_rank0']:.1f} %)" if d else "—"
+        print(f"| {i} | {wl} | {c['launch']} | `{c['kernel']}` | {r['value']:,.0f} | {1e3 * r['ms_per_step']:.2f} | {rf['achieved']:,.0f} | "
+              f"{100 * rf['frac']:.1f} | {dd} |")
+    first = json.loads(open(path).readline())
+    cb = first.get("cpu_baseline")
+    if cb:
+        print(f"\nCPU baseline of line 1 (`cpu_baseline`): {cb['value']} Mpx/s on {cb['cores']} thread ({cb['kind']}); "
+              f"{cb['all_cores']['value']:,.0f} Mpx/s on {cb['all_cores']['cores']} threads. {cb['jvm']}.")
+    cc = first["roofline"].get("copy_ceiling")
+    if cc:
+        print(f"Measured NT-copy ceiling in the same run: {cc['GB/s']:,.0f} GB/s = {100 * cc['frac_of_peak']:.1f} % of 8 TB/s; "
+              f"the headline kernel runs at {100 * cc['kernel_frac_of_copy']:.1f} % of it.")
+
+
+if __name__ == "__main__":
+    main()

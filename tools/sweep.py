@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Throughput sweep over frame sizes x J:a:b x factor x order class (device-resident, batched so that every
-step moves >= 512 MiB and is not launch-bound).  Writes a markdown table; run on the GPU box:
+step moves >= 768 MB of ALGORITHMIC bytes and is not launch-bound -- round 1 batched by input size, which left the
+f = 4 / f = 8 launches 8-64x smaller than the f = 1 ones and made them look 10 points worse than the kernel is).
+Writes a markdown table; run on the GPU box:
     python tools/sweep.py > gpurun_out/sweep.md
 """
 import ctypes as C
@@ -35,7 +37,8 @@ for (W, H), (a, b), f, (oname, op) in itertools.product(SHAPES, MODES, (1, 2, 4,
     cp = csic.make_c_params(W, H, a, b, 3, 3, 2, f, op)
     plan = csic.Plan(cp, 0)
     in_px, out_px = W * H, plan.out_width * plan.out_height
-    fps = max(1, -(-(512 << 20) // (in_px * 4)))
+    fps = max(1, -(-(768 * 1000 * 1000) // plan.algorithmic_bytes))
+    fps = max(1, min(fps, (12 << 30) // (in_px * 4)))          # at most 12 GiB of input per step (ring of 3)
     nring = 3
     ins = [torch.empty(in_px * fps, dtype=torch.int32, device=dev) for _ in range(nring)]
     outs = [torch.empty(out_px * fps, dtype=torch.int32, device=dev) for _ in range(nring)]

@@ -11,6 +11,7 @@
 #include <hsa/hsa_ext_amd.h>
 #include <hsa/hsa_ven_amd_loader.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <string>
@@ -261,6 +262,68 @@ int main(int argc, char **argv)
     report("aql barrier=0 acq/rel none", false, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE);
     report("aql barrier=1 acq/rel none", true, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE);
     report("aql barrier=0 acq/rel system", false, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_SYSTEM);
+    // ---- dispatch timeline from the CP's own timestamps (hsa_amd_profiling_get_dispatch_time): one 64-frame round per
+    // configuration with a completion signal on every packet.  rocprofv3's kernel trace cannot show this: its queue
+    // interception serialises the dispatches (max 1 kernel in flight, 6-8 us per frame under the profiler).
+    auto timeline = [&](const char *name, int Q, bool barrier_bit) {
+        std::vector<hsa_signal_t> sig(N);
+        for (int k = 0; k < N; ++k) HK(hsa_signal_create(1, 0, nullptr, &sig[k]));
+        for (int j = 0; j < Q; ++j) HK(hsa_amd_profiling_set_profiler_enabled(qs[j], 1));
+        for (int rep = 0; rep < 3; ++rep) {                              // the last repetition is reported
+            for (int k = 0; k < N; ++k) hsa_signal_store_relaxed(sig[k], 1);
+            uint64_t idx[MAXQ]; int cnt[MAXQ], pos[MAXQ] = {0};
+            for (int j = 0; j < Q; ++j) { cnt[j] = N / Q + (j < N % Q ? 1 : 0); idx[j] = hsa_queue_add_write_index_relaxed(qs[j], cnt[j]); }
+            for (int k = 0; k < N; ++k) {
+                const int j = k % Q;
+                auto *rg = static_cast<hsa_kernel_dispatch_packet_t *>(qs[j]->base_address);
+                hsa_kernel_dispatch_packet_t *pk = &rg[(idx[j] + pos[j]) & (qs[j]->size - 1)];
+                pk->workgroup_size_x = d[k].block.x; pk->workgroup_size_y = d[k].block.y; pk->workgroup_size_z = d[k].block.z;
+                pk->reserved0 = 0;
+                pk->grid_size_x = d[k].grid.x * d[k].block.x; pk->grid_size_y = d[k].grid.y * d[k].block.y; pk->grid_size_z = d[k].grid.z * d[k].block.z;
+                pk->private_segment_size = 0; pk->group_segment_size = 0;
+                pk->kernel_object = f.kernel_object;
+                pk->kernarg_address = dk + k * kstride;
+                pk->reserved2 = 0;
+                pk->completion_signal = sig[k];
+                const int bar = (barrier_bit || pos[j] == 0) ? 1 : 0;
+                const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (bar << HSA_PACKET_HEADER_BARRIER) |
+                                        ((barrier_bit ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                                        ((barrier_bit ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE) << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+                __atomic_store_n(reinterpret_cast<uint32_t *>(pk), header | (uint32_t(3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS) << 16), __ATOMIC_RELEASE);
+                ++pos[j];
+            }
+            for (int j = 0; j < Q; ++j) hsa_signal_store_screlease(qs[j]->doorbell_signal, idx[j] + cnt[j] - 1);
+            for (int k = 0; k < N; ++k)
+                if (hsa_signal_wait_scacquire(sig[k], HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED) >= 1) { printf("TIMEOUT (timeline)\n"); exit(2); }
+        }
+        uint64_t freq = 0;
+        HK(hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &freq));
+        std::vector<std::pair<uint64_t, int>> ev;
+        uint64_t t0 = ~0ull, t1 = 0;
+        double sum = 0;
+        for (int k = 0; k < N; ++k) {
+            hsa_amd_profiling_dispatch_time_t t{};
+            HK(hsa_amd_profiling_get_dispatch_time(f.agent, sig[k], &t));
+            ev.push_back({t.start, +1}); ev.push_back({t.end, -1});
+            if (t.start < t0) t0 = t.start;
+            if (t.end > t1) t1 = t.end;
+            sum += double(t.end - t.start);
+        }
+        std::sort(ev.begin(), ev.end());
+        int cur = 0, mx = 0; double area = 0; uint64_t last = t0;
+        for (auto &e : ev) { area += double(e.first - last) * cur; last = e.first; cur += e.second; if (cur > mx) mx = cur; }
+        const double us = 1e6 / double(freq);
+        printf("timeline %-28s span %7.2f us = %5.2f us/frame; mean kernel %5.2f us; kernels in flight: mean %.2f, max %d\n", name,
+               (t1 - t0) * us, (t1 - t0) * us / N, sum * us / N, area / double(t1 - t0), mx);
+        fflush(stdout);
+        for (int j = 0; j < Q; ++j) HK(hsa_amd_profiling_set_profiler_enabled(qs[j], 0));
+        for (int k = 0; k < N; ++k) hsa_signal_destroy(sig[k]);
+    };
+    timeline("1 queue, barrier bit", 1, true);
+    timeline("1 queue, no barrier bit", 1, false);
+    timeline("2 queues, no barrier bit", 2, false);
+    timeline("4 queues, no barrier bit", 4, false);
+
     for (int Q : {1, 2, 3, 4, 6, 8}) report_mq(Q, rounds);
     for (int Q : {1, 2, 4, 8}) report_mq(Q, 1);          // one 64-frame "graph launch" at a time, host waits in between
     for (int i = 0; i < MAXQ; ++i) { hsa_queue_destroy(qs[i]); hsa_signal_destroy(dones[i]); }
