@@ -138,7 +138,12 @@ def load_traffic(config, kernel_name, world):
 class Workload:
     """One rank's share of one scaling mode: its stripe, plan, ring of device frames and the step function."""
 
-    def __init__(self, args, csic, torch, dev, dev_index, world, rank, scaling):
+    def __init__(self, args, csic, torch, dev, dev_index, world, rank, scaling, issue="serial"):
+        """issue: how the steps reach the GPU --
+        "serial": one eager launch per step on the launch stream (N = 1 headline: the roofline contract);
+        "hip"   : the same launches from a frame graph, CSIC_FRAME_GRAPH_HIP (hipGraph chains ordered with the stream);
+        "direct": the same launches from a frame graph, CSIC_FRAME_GRAPH_DIRECT (AQL packets without barrier bits on the
+                  library's queues, gated by and awaited on the launch stream through HIP signal memory)."""
         N = csic._native
         lib = N.lib()
         self.N, self.lib, self.torch, self.dev, self.args = N, lib, torch, dev, args
@@ -171,7 +176,10 @@ class Workload:
 
         # ---- ring of distinct frames, generated on the device -----------------------------------
         step_in_bytes = self.in_px * 4 * fps
-        self.nring = max(2, min(64, (args.ring_mib << 20) // max(step_in_bytes, 1)))
+        # frame-graph issue modes replay the whole ring per launch: more (smaller) steps per replay amortise the
+        # ~20-40 us of signal hand-offs of a stream-ordered direct launch
+        ring_cap = 64 if issue == "serial" else 256
+        self.nring = max(2, min(ring_cap, (args.ring_mib << 20) // max(step_in_bytes, 1)))
         self.stream = torch.cuda.current_stream(dev)
         self.sh = C.c_void_p(self.stream.cuda_stream)
         self.ins = [torch.empty(self.in_px * fps, dtype=torch.int32, device=dev) for _ in range(self.nring)]
@@ -183,8 +191,8 @@ class Workload:
         self.out_ptrs = [C.c_void_p(t.data_ptr()) for t in self.outs]
         self.graphs = []
         self.step_graph = None
-        self.direct = None
         self.world = world
+        self.issue = issue
         self._build_step()
 
     # -- how one step is issued -------------------------------------------------------------------
@@ -192,15 +200,23 @@ class Workload:
         args, lib, ph, nring, sh = self.args, self.lib, self.plan._h, self.nring, self.sh
         in_ptrs, out_ptrs, fps = self.in_ptrs, self.out_ptrs, self.fps
         import csic_amd as csic
+        backend = "direct" if self.issue == "direct" else "hip"
+        branches = (args.direct_queues if backend == "direct" else args.graph_branches) or None
+
+        def describe(g, what):
+            if g.backend == "direct":
+                return (f"{what} replayed from a frame graph, CSIC_FRAME_GRAPH_DIRECT: pre-built AQL packets without barrier bits on "
+                        f"{g.branches} user-mode queue(s), " + ("gated by and awaited on the launch stream (HIP signal memory)"
+                                                                 if g.stream_ordered else "host-ordered (no HIP signal memory on this runtime)"))
+            return (f"{what} replayed from a frame graph, CSIC_FRAME_GRAPH_HIP: {g.branches} hipGraph chain(s) ordered with the launch stream")
+
         if self.per_frame_graph:
-            # BASELINE.json configs[4] literally: a hipGraph of per-frame launches, one graph per ring slot
-            # (csic_frame_graph_*: one kernel node per frame, `--graph-branches` independent chains)
+            # BASELINE.json configs[4] literally: pre-recorded per-frame launches, one graph per ring slot
             for k in range(nring):
                 fin = [self.ins[k][j * self.in_px:(j + 1) * self.in_px] for j in range(fps)]
                 fout = [self.outs[k][j * self.out_px:(j + 1) * self.out_px] for j in range(fps)]
-                self.graphs.append(csic.FrameGraph(self.plan, fin, fout, branches=args.graph_branches or None))
-            self.launch_desc = (f"{fps} per-frame launches per step replayed from a frame graph, CSIC_FRAME_GRAPH_HIP: "
-                                f"{self.graphs[0].branches} hipGraph chain(s) ordered with the launch stream")
+                self.graphs.append(csic.FrameGraph(self.plan, fin, fout, branches=branches, backend=backend))
+            self.launch_desc = describe(self.graphs[0], f"{fps} per-frame launches per step")
 
             def step(i):
                 self.graphs[i % nring].launch(self.stream)
@@ -216,55 +232,14 @@ class Workload:
             def step(i):
                 return lib.csic_process_batch_device(ph, in_ptrs[i % nring], out_ptrs[i % nring], fps, sh)
         self.step = step
-        # N > 1: the steps are issued from a pre-built frame graph over the ring (CSIC_FRAME_GRAPH_HIP: the SAME
-        # launches, one kernel node per step, in the library's default number of chains for this stripe size --
-        # chain 0 on the launch stream, the others on internal streams, all ordered with the launch stream).  A
+        # issue = "hip" / "direct": the one-launch steps come from a pre-built frame graph over the ring -- the SAME
+        # launches, one per step, replayed nring steps at a time on the launch stream (ragged ends stay eager).  A
         # strong-scaling stripe at N = 8 is a 3 us launch: a Python loop cannot enqueue those fast enough, and
         # independent steps that overlap hide each other's launch boundary (profiles/r02_small_launch.md).
-        # N = 1 keeps plain eager launches on one stream (the roofline contract: HIP events around serial launches).
-        use = args.step_graph == "on" or (args.step_graph == "auto" and self.world > 1)
-        if use and not self.per_frame_graph and fps == 1 and args.streams <= 1:
-            self.step_graph = csic.FrameGraph(self.plan, self.ins, self.outs, branches=args.step_chains or None)
-            self.launch_desc = (f"one launch per step; {nring} consecutive steps (the ring) replayed from a frame graph, "
-                                f"CSIC_FRAME_GRAPH_HIP, {self.step_graph.branches} chain(s) ordered with the launch stream")
-
-    # -- the same steps through the direct-dispatch engine (side measurement) ------------------------
-    def build_direct(self, K):
-        """CSIC_FRAME_GRAPH_DIRECT graphs covering exactly K steps: whole-ring graphs plus one for the remainder."""
-        import csic_amd as csic
-        q = self.args.direct_queues or None
-        if self.per_frame_graph:
-            fps = self.fps
-            self.direct = []
-            for k in range(self.nring):
-                fin = [self.ins[k][j * self.in_px:(j + 1) * self.in_px] for j in range(fps)]
-                fout = [self.outs[k][j * self.out_px:(j + 1) * self.out_px] for j in range(fps)]
-                self.direct.append(csic.FrameGraph(self.plan, fin, fout, branches=q, backend="direct"))
-            self.direct_desc = (f"{fps} per-frame launches per step as pre-built AQL packets on {self.direct[0].branches} "
-                                "user-mode queue(s), no barrier bit (CSIC_FRAME_GRAPH_DIRECT)")
-            return
-        main = csic.FrameGraph(self.plan, self.ins, self.outs, branches=q, backend="direct")
-        rem = K % self.nring
-        self.direct = [main, csic.FrameGraph(self.plan, self.ins[:rem], self.outs[:rem], branches=q, backend="direct") if rem else None]
-        self.direct_desc = (f"one launch per step; steps pre-built as AQL packets on {main.branches} user-mode queue(s), "
-                            "no barrier bit (CSIC_FRAME_GRAPH_DIRECT), host wall clock")
-
-    def run_direct(self, K):
-        """Submits exactly K steps and waits for all of them."""
-        if self.per_frame_graph:
-            for i in range(K):
-                self.direct[i % self.nring].submit()
-            for g in self.direct:
-                g.wait()
-            return
-        main, rem = self.direct
-        for _ in range(K // self.nring):
-            main.submit()
-        if rem is not None:
-            rem.submit()
-        main.wait()
-        if rem is not None:
-            rem.wait()
+        if self.issue != "serial" and not self.per_frame_graph and fps == 1 and args.streams <= 1:
+            self.step_graph = csic.FrameGraph(self.plan, self.ins, self.outs, backend=backend,
+                                              branches=(args.direct_queues if backend == "direct" else args.step_chains) or None)
+            self.launch_desc = describe(self.step_graph, f"one launch per step; {nring} consecutive steps (the ring)")
 
     def run_steps(self, first, count):
         """Issues steps first .. first+count-1 (asynchronous).  Returns the OR of the launch statuses."""
@@ -289,9 +264,6 @@ class Workload:
             g.close()
         if self.step_graph is not None:
             self.step_graph.close()
-        for g in (self.direct or []):
-            if g is not None:
-                g.close()
         self.plan.close()
         self.ins = self.outs = None
         self.torch.cuda.empty_cache()
@@ -353,12 +325,18 @@ def timed_run(wl, args, torch, dist, world, backend, dev):
     return elapsed, kern_ms_avg
 
 
-def timed_direct(wl, args, torch, dist, world, backend, dev):
-    """The same K steps through the direct-dispatch engine (CSIC_FRAME_GRAPH_DIRECT): warm-up, then exactly K steps
-    between barrier + synchronize on both sides, host wall clock, max over ranks.  A side measurement: these
-    launches are not on a HIP stream, so there are no HIP events around them."""
-    K = args.steps
-    wl.build_direct(K)
+def host_ordered_direct(wl, K, torch, dist, world, backend, dev):
+    """issue=direct only: the same graphs through csic_frame_graph_submit / _wait (ordered by the host, no gate and no
+    stream waits), wall clock between barriers; whole graph replays only, so the step count is rounded down."""
+    graphs = wl.graphs if wl.per_frame_graph else [wl.step_graph]
+    per = 1 if wl.per_frame_graph else wl.nring
+    reps = max(1, K // per)
+
+    def run():
+        for i in range(reps):
+            graphs[i % len(graphs)].submit()
+        for g in graphs:
+            g.wait()
 
     def barrier():
         if world > 1:
@@ -366,21 +344,17 @@ def timed_direct(wl, args, torch, dist, world, backend, dev):
         torch.cuda.synchronize(dev)
 
     torch.cuda.synchronize(dev)
-    if args.prewarm_ms > 0:
-        t_end = time.perf_counter() + args.prewarm_ms * 1e-3
-        while time.perf_counter() < t_end:
-            wl.run_direct(min(K, 4 * wl.nring) if wl.fps == 1 else min(K, 8))
-    wl.run_direct(K)                                              # warm-up: one full pass
+    run()
     barrier()
     t0 = time.perf_counter()
-    wl.run_direct(K)
+    run()
     barrier()
-    elapsed = time.perf_counter() - t0
+    el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed
+        el = float(t.item())
+    return el, reps * per
 
 
 def main(argv=None):
@@ -418,19 +392,21 @@ def main(argv=None):
     ap.add_argument("--graph-branches", type=int, default=0,
                     help="--per-frame-graph: number of independent chains in the frame graph (0 = library default, "
                          "1 = strictly serial, what capturing a loop on one stream gives)")
-    ap.add_argument("--step-graph", default="auto", choices=["auto", "on", "off"],
-                    help="issue the (one-launch) steps from a pre-built frame graph over the ring instead of a Python loop "
-                         "(auto: N>1 yes, N=1 no)")
+    ap.add_argument("--issue", default="auto", choices=["auto", "serial", "hip", "direct"],
+                    help="how the steps reach the GPU (see Workload): serial = one eager launch per step on the launch stream; hip / "
+                         "direct = the same launches replayed from a frame graph (CSIC_FRAME_GRAPH_HIP chains / CSIC_FRAME_GRAPH_DIRECT "
+                         "AQL packets without barrier bits), both ordered with the launch stream and timed by the same HIP events.  "
+                         "auto: N=1 serial (the roofline contract: the profiler's per-kernel average must describe the timed launches), "
+                         "N>1 direct (a 3 us stripe launch needs pre-built launches; falls back to hip if the runtime refuses)")
     ap.add_argument("--step-chains", type=int, default=0,
-                    help="--step-graph: independent hipGraph chains among consecutive steps (0 = library default for the "
-                         "stripe size, 1 = single-stream order)")
+                    help="issue hip: hipGraph chains among consecutive steps (0 = library default for the stripe size, 1 = single-stream order)")
     ap.add_argument("--direct-queues", type=int, default=0,
-                    help="queues of the direct-dispatch side measurement (0 = library default for the frame size)")
+                    help="issue direct: user-mode queues (0 = library default for the frame size)")
     ap.add_argument("--direct", action="store_true",
-                    help="N=1: also time the same K steps through the direct-dispatch engine and report them beside the "
-                         "headline (default at N>1; off by default at N=1 so that `rocprofv3 --stats` of the default command "
-                         "sees only the serial HIP-stream launches the roofline is measured on)")
-    ap.add_argument("--no-direct", action="store_true", help="N>1: skip the direct-dispatch side measurement")
+                    help="N=1: also time the same K steps with issue=direct and report them beside the headline as `direct_dispatch` "
+                         "(off by default at N=1 so that `rocprofv3 --stats` of the default command sees only the serial launches)")
+    ap.add_argument("--no-side", action="store_true",
+                    help="N>1: skip the side measurement of the other issue mode (`hip_streams`)")
     ap.add_argument("--streams", type=int, default=1,
                     help="EXPERIMENT (default 1 = the contract): issue consecutive steps round-robin on this many HIP "
                          "streams so that one frame's ramp-up overlaps the previous frame's drain.  Per-kernel durations "
@@ -479,7 +455,25 @@ def main(argv=None):
     headline_mode = "weak" if args.scaling == "weak" else "strong"
 
     # ---- headline run --------------------------------------------------------------------------------
-    wl = Workload(args, csic, torch, dev, dev_index, world, rank, headline_mode)
+    if args.issue != "auto":
+        issue = args.issue
+    else:
+        issue = "serial" if world == 1 else "direct"
+    issue_note = None
+    try:
+        wl = Workload(args, csic, torch, dev, dev_index, world, rank, headline_mode, issue)
+    except csic.CsicRuntimeError as exc:
+        if issue != "direct":
+            raise
+        issue_note = f"direct dispatch unavailable ({exc}); fell back to issue=hip"
+        issue = "hip"
+        wl = Workload(args, csic, torch, dev, dev_index, world, rank, headline_mode, issue)
+    if world > 1:                                                   # every rank must take the same path
+        flag = allsum(1.0 if issue == "direct" else 0.0)
+        if issue == "direct" and flag != world:
+            wl.close()
+            issue, issue_note = "hip", "direct dispatch unavailable on some rank; all ranks use issue=hip"
+            wl = Workload(args, csic, torch, dev, dev_index, world, rank, headline_mode, issue)
     elapsed, kern_ms_avg = timed_run(wl, args, torch, dist, world, args.backend, dev)
     total_px = allsum(float(wl.in_px) * wl.fps * K)                # real per-rank pixel counts, summed
     value = total_px / elapsed / 1e6
@@ -513,36 +507,52 @@ def main(argv=None):
         torch.cuda.synchronize(dev)
         copy_gbs = 2.0 * npx * 4 * ncopy / (c0.elapsed_time(c1) * 1e-3) / 1e9
 
-    # ---- the same K steps through the direct-dispatch engine (side measurement, every N) ---------------
-    direct = None
-    want_direct = args.direct or (world > 1 and not args.no_direct)
-    if want_direct and args.streams <= 1 and (wl.fps == 1 or wl.per_frame_graph):
-        eld = timed_direct(wl, args, torch, dist, world, args.backend, dev)
-        pxd = allsum(float(wl.in_px) * wl.fps * K)
-        per_launch_ms = eld * 1e3 / K / wl.launches_per_step
-        direct = {"value": round(pxd / eld / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(eld * 1e3 / K, 5), "steps": K,
-                  "scaling": headline_mode, "launch": wl.direct_desc,
-                  "roofline_frac_rank0": round(wl.alg_bytes / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                  "note": "same plan, same ring, same kernels as the headline; `value` above is the HIP-stream path, this is "
-                          "what csic_frame_graph_submit/_wait deliver for a pre-recorded stream of frames"}
-
     head = {"stripe_rows": wl.stripe_rows, "global_rows": wl.global_rows, "nring": wl.nring, "kernel": wl.plan.kernel_name,
             "launch": wl.launch_desc, "alg_bytes": wl.alg_bytes, "lpf": wl.lpf, "out_px": wl.out_px, "in_px": wl.in_px,
             "fps": wl.fps}
+    head_host_ordered = None
+    if issue == "direct" and (wl.step_graph is not None or wl.per_frame_graph):
+        elh, nsteps = host_ordered_direct(wl, K, torch, dist, world, args.backend, dev)
+        pxh = allsum(float(wl.in_px) * wl.fps * nsteps)
+        head_host_ordered = {"value": round(pxh / elh / 1e6, 1), "ms_per_step": round(elh * 1e3 / nsteps, 5), "steps": nsteps,
+                             "roofline_frac_rank0": round(wl.alg_bytes * wl.launches_per_step * nsteps / elh / 1e9 / HBM_PEAK_GBS, 4),
+                             "how": "the headline's graphs through csic_frame_graph_submit/_wait: no gate, no stream waits, host wall clock"}
     wl.close()
 
-    # ---- N > 1: the other scaling mode, measured in the same process, reported beside the headline ----
-    other = None
-    if world > 1 and args.scaling in ("strong", "both", "weak"):
-        omode = "weak" if headline_mode == "strong" else "strong"
-        wl2 = Workload(args, csic, torch, dev, dev_index, world, rank, omode)
-        el2, km2 = timed_run(wl2, args, torch, dist, world, args.backend, dev)
-        px2 = allsum(float(wl2.in_px) * wl2.fps * K)
-        other = {"scaling": omode, "value": round(px2 / el2 / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(el2 * 1e3 / K, 5),
-                 "stripe_rows_per_gpu": wl2.stripe_rows, "global_rows": wl2.global_rows, "launch": wl2.launch_desc,
-                 "roofline_frac_rank0": round(wl2.alg_bytes / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                 "kernel_ms_avg_rank0": round(km2, 5)}
-        wl2.close()
+    def side(scaling, how):
+        """The same K steps in another scaling mode / issue mode, same process, same timing method."""
+        w2 = Workload(args, csic, torch, dev, dev_index, world, rank, scaling, how)
+        el2, km2 = timed_run(w2, args, torch, dist, world, args.backend, dev)
+        px2 = allsum(float(w2.in_px) * w2.fps * K)
+        res = {"scaling": scaling, "value": round(px2 / el2 / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(el2 * 1e3 / K, 5),
+               "steps": K, "stripe_rows_per_gpu": w2.stripe_rows, "global_rows": w2.global_rows, "launch": w2.launch_desc,
+               "roofline_frac_rank0": round(w2.alg_bytes / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "kernel_ms_avg_rank0": round(km2, 5)}
+        if how == "direct" and (w2.step_graph is not None or w2.per_frame_graph):
+            elh, nsteps = host_ordered_direct(w2, K, torch, dist, world, args.backend, dev)
+            pxh = allsum(float(w2.in_px) * w2.fps * nsteps)
+            res["host_ordered"] = {"value": round(pxh / elh / 1e6, 1), "ms_per_step": round(elh * 1e3 / nsteps, 5), "steps": nsteps,
+                                   "roofline_frac_rank0": round(w2.alg_bytes * w2.launches_per_step * nsteps / elh / 1e9 / HBM_PEAK_GBS, 4),
+                                   "how": "csic_frame_graph_submit/_wait: no gate, no stream waits, host wall clock"}
+        w2.close()
+        return res
+
+    sides = {}
+    can_graph = args.streams <= 1 and (head["fps"] == 1 or (args.per_frame_graph and head["fps"] > 1))
+    if world > 1:
+        # the other scaling mode, issued the same way as the headline
+        sides["weak" if headline_mode == "strong" else "strong"] = side("weak" if headline_mode == "strong" else "strong", issue)
+        if can_graph and not args.no_side:
+            other_issue = "hip" if issue == "direct" else "direct"
+            try:
+                sides["hip_streams" if other_issue == "hip" else "direct_dispatch"] = side(headline_mode, other_issue)
+            except csic.CsicRuntimeError as exc:
+                sides["direct_dispatch"] = {"unavailable": str(exc)}
+    elif args.direct and can_graph and issue != "direct":
+        try:
+            sides["direct_dispatch"] = side(headline_mode, "direct")
+        except csic.CsicRuntimeError as exc:
+            sides["direct_dispatch"] = {"unavailable": str(exc)}
 
     if rank == 0:
         traffic, traffic_note = load_traffic(args.config, head["kernel"], world)
@@ -567,6 +577,7 @@ def main(argv=None):
                 "world_size_formed": formed,
                 "kernel": head["kernel"],
                 "launch": head["launch"],
+                "issue": issue,
                 "streams": args.streams,
             },
             "roofline": {
@@ -583,10 +594,12 @@ def main(argv=None):
                           "diagnostic, one event pair per step (inflated by the marker packets)",
             },
         }
-        if other is not None:
-            line[other["scaling"]] = other
-        if direct is not None:
-            line["direct_dispatch"] = direct
+        for key, obj in sides.items():
+            line[key] = obj
+        if head_host_ordered is not None:
+            line["direct_host_ordered"] = head_host_ordered
+        if issue_note:
+            line["config"]["issue_note"] = issue_note
         if copy_gbs:
             line["roofline"]["copy_ceiling"] = {
                 "GB/s": round(copy_gbs, 1), "frac_of_peak": round(copy_gbs / HBM_PEAK_GBS, 4),

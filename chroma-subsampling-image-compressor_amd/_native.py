@@ -21,7 +21,7 @@ ROUND_FLOOR_HW, ROUND_TRUNC_SW = 0, 1
 FMT_ARGB8888, FMT_YCBCR888X = 0, 1
 TUNE_VARIANT, TUNE_FORCE_GENERIC, TUNE_NONTEMPORAL, TUNE_NO_VECTOR, TUNE_BLOCK_THREADS = 1, 2, 3, 4, 5
 FRAME_GRAPH_HIP, FRAME_GRAPH_DIRECT = 0, 1
-FRAME_GRAPH_DEFAULT_BRANCHES, FRAME_GRAPH_DEFAULT_QUEUES = 4, 4
+FRAME_GRAPH_DEFAULT_BRANCHES, FRAME_GRAPH_DEFAULT_QUEUES = 4, 3
 PIPELINE_STAGED, PIPELINE_ZERO_COPY = 0, 1
 
 
@@ -94,6 +94,7 @@ PROTOTYPES = {
     "csic_frame_graph_submit": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "csic_frame_graph_wait": (C.c_int, [C.c_void_p, C.c_int64]),
     "csic_frame_graph_backend": (C.c_int, [C.c_void_p]),
+    "csic_frame_graph_stream_ordered": (C.c_int, [C.c_void_p]),
     "csic_frame_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "csic_frame_graph_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "csic_frame_graph_destroy": (C.c_int, [C.c_void_p]),

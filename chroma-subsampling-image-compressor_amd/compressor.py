@@ -132,8 +132,9 @@ class FrameGraph:
     pixels; they may live anywhere on the plan's device (views into one big tensor, or separate allocations).
     backend "hip": `branches` hipGraph chains, launch(stream) is asynchronous and ordered with the stream.
     backend "direct": AQL packets without barrier bits on the library's own user-mode queues (`branches` =
-    queues); submit() starts immediately and returns a ticket, wait() blocks the host; launch(stream) is the
-    synchronous composition stream-sync + submit + wait."""
+    queues); submit() starts immediately and returns a ticket, wait() blocks the host; launch(stream) is
+    asynchronous and ordered with the stream on the device when `stream_ordered` (HIP signal memory shared with
+    the queues), else the synchronous composition stream-sync + submit + wait."""
 
     BACKENDS = {"hip": N.FRAME_GRAPH_HIP, "direct": N.FRAME_GRAPH_DIRECT}
 
@@ -159,10 +160,11 @@ class FrameGraph:
         nf, nb = C.c_int32(), C.c_int32()
         N.check(N.lib().csic_frame_graph_count(self._h, C.byref(nf), C.byref(nb)))
         self.nframes, self.branches = nf.value, nb.value
+        self.stream_ordered = bool(N.lib().csic_frame_graph_stream_ordered(self._h))
 
     def launch(self, stream=None) -> None:
-        """Replays the graph on `stream` (a torch.cuda.Stream; default: torch's current stream).  Asynchronous for
-        the "hip" backend, host-synchronous for "direct"."""
+        """Replays the graph on `stream` (a torch.cuda.Stream; default: torch's current stream), ordered with it.
+        Asynchronous when `stream_ordered`."""
         import torch
         s = torch.cuda.current_stream(self.device) if stream is None else stream
         N.check(N.lib().csic_frame_graph_launch(self._h, C.c_void_p(s.cuda_stream)))

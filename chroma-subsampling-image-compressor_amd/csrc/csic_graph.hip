@@ -25,13 +25,17 @@
 //    barrier bit and an agent-scope acquire, a closing barrier-AND packet per queue carries the release and the
 //    completion signal.  The kernels are the ones HIP loaded: their kernel objects are found among the process's
 //    loaded executables (hsa_ven_amd_loader_iterate_executables) under the name hipKernelNameRefByPtr reports.
-//    These queues are not HIP streams: a submission starts immediately and is awaited on the host
-//    (csic_frame_graph_submit / _wait); csic_frame_graph_launch() on a DIRECT graph is the synchronous
-//    composition stream-sync + submit + wait.
+//    These queues are not HIP streams.  csic_frame_graph_submit / _wait order a submission by the host.
+//    csic_frame_graph_launch(graph, stream) orders it with a HIP stream ON THE DEVICE: the signals are HIP "signal
+//    memory" (the value word of an HSA signal), so the stream opens a gate packet at the head of every queue with
+//    hipStreamWriteValue64 and waits for the closing packets with hipStreamWaitValue64 -- asynchronous, no host
+//    round trip (see `stream_ordered` below; without that runtime feature launch() degrades to sync + submit + wait).
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 #include <hsa/hsa_ven_amd_loader.h>
+#include <hsa/amd_hsa_signal.h>
 
+#include <cstddef>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -292,6 +296,17 @@ struct csic_frame_graph {
     hsa_signal_t done[DIRECT_SLOTS][MAX_QUEUES] = {};
     bool have_signals = false;
     int64_t next_ticket = 0, waited = 0;        // tickets < waited have completed and been observed
+    // Stream-ordered launches.  HIP's "signal memory" (hipExtMallocWithFlags(.., hipMallocSignalMemory)) is the value
+    // word of an HSA signal the runtime created; the amd_signal_t it belongs to starts 8 bytes earlier
+    // (hsa/amd_hsa_signal.h).  Such a signal works on both sides: hipStreamWriteValue64 / hipStreamWaitValue64 on the
+    // word, AQL barrier packets (and hsa_signal_wait) on the handle -- a HIP stream can open a gate in our queues and
+    // wait for their closing packets without the host in between.  Verified at creation (kind == USER, 64-byte aligned);
+    // if the runtime does not offer it the graph falls back to plain HSA signals and host-ordered launches.
+    bool stream_ordered = false;
+    uint64_t *sigmem[DIRECT_SLOTS][1 + MAX_QUEUES] = {};   // [slot][0] = gate, [slot][1 + j] = queue j done (HIP allocations)
+    hsa_signal_t gate[DIRECT_SLOTS] = {};
+    hipEvent_t consumed[DIRECT_SLOTS] = {};                 // recorded on the launch stream behind its waits
+    bool slot_on_stream[DIRECT_SLOTS] = {};
 };
 
 static void graph_free(csic_frame_graph *g)
@@ -302,10 +317,15 @@ static void graph_free(csic_frame_graph *g)
     if (g->fork) (void)hipEventDestroy(g->fork);
     for (auto s : g->streams) if (s) (void)hipStreamSynchronize(s);        // pooled: not destroyed here
     if (g->d_kernarg) (void)hipFree(g->d_kernarg);
-    if (g->have_signals)
+    if (g->have_signals && !g->stream_ordered)
         for (int s = 0; s < DIRECT_SLOTS; ++s)
             for (int j = 0; j < MAX_QUEUES; ++j)
                 if (g->done[s][j].handle) (void)hsa_signal_destroy(g->done[s][j]);
+    for (int s = 0; s < DIRECT_SLOTS; ++s) {
+        for (int j = 0; j < 1 + MAX_QUEUES; ++j)
+            if (g->sigmem[s][j]) (void)hipFree(g->sigmem[s][j]);
+        if (g->consumed[s]) (void)hipEventDestroy(g->consumed[s]);
+    }
     if (g->eng) engine_release(g->eng);
     delete g;
 }
@@ -394,6 +414,34 @@ static int build_direct(csic_frame_graph *g, csic_plan *plan, const void *const 
         p.kernarg_address = static_cast<uint8_t *>(g->d_kernarg) + (size_t)k * stride;
         try { g->packets[k % g->branches].push_back(p); } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
     }
+    // signals: HIP signal memory when the runtime offers it (stream-ordered launches), plain HSA signals otherwise
+    int can = 0;
+    bool shared = hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, g->device) == hipSuccess && can != 0;
+    for (int s = 0; shared && s < DIRECT_SLOTS; ++s)
+        for (int j = 0; shared && j < 1 + g->branches; ++j) {
+            void *p = nullptr;
+            if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess) { (void)hipGetLastError(); shared = false; break; }
+            g->sigmem[s][j] = static_cast<uint64_t *>(p);
+            const uintptr_t base = reinterpret_cast<uintptr_t>(p) - offsetof(amd_signal_t, value);
+            if ((base & (AMD_SIGNAL_ALIGN_BYTES - 1)) || reinterpret_cast<const volatile amd_signal_t *>(base)->kind != AMD_SIGNAL_KIND_USER) shared = false;
+        }
+    if (shared) {
+        for (int s = 0; s < DIRECT_SLOTS; ++s) {
+            g->gate[s].handle = reinterpret_cast<uint64_t>(g->sigmem[s][0]) - offsetof(amd_signal_t, value);
+            hsa_signal_store_relaxed(g->gate[s], 0);
+            for (int j = 0; j < g->branches; ++j) {
+                g->done[s][j].handle = reinterpret_cast<uint64_t>(g->sigmem[s][1 + j]) - offsetof(amd_signal_t, value);
+                hsa_signal_store_relaxed(g->done[s][j], 0);
+            }
+            HIP_TRY(hipEventCreateWithFlags(&g->consumed[s], hipEventDisableTiming));
+        }
+        g->stream_ordered = true;
+        g->have_signals = true;
+        return CSIC_OK;
+    }
+    for (int s = 0; s < DIRECT_SLOTS; ++s)
+        for (int j = 0; j < 1 + MAX_QUEUES; ++j)
+            if (g->sigmem[s][j]) { (void)hipFree(g->sigmem[s][j]); g->sigmem[s][j] = nullptr; }
     for (int s = 0; s < DIRECT_SLOTS; ++s)
         for (int j = 0; j < g->branches; ++j) {
             g->have_signals = true;
@@ -411,10 +459,14 @@ static inline void publish(void *slot, uint16_t header, uint16_t setup)
 static int wait_slot(csic_frame_graph *g, int64_t ticket)
 {
     const int slot = (int)(ticket % DIRECT_SLOTS);
-    for (int j = 0; j < g->branches; ++j) {
-        const hsa_signal_value_t v = hsa_signal_wait_scacquire(g->done[slot][j], HSA_SIGNAL_CONDITION_LT, 1, WAIT_TICKS, HSA_WAIT_STATE_BLOCKED);
-        if (v >= 1) return set_error(CSIC_EHIP, "direct dispatch: queue %d did not finish submission %lld in time", j, (long long)ticket);
+    if (g->slot_on_stream[slot]) {              // a stream-ordered launch: done when the stream has passed its waits
+        HIP_TRY(hipEventSynchronize(g->consumed[slot]));
+        g->slot_on_stream[slot] = false;
+        return CSIC_OK;
     }
+    // done[slot][0] is completed by queue 0's closing packet, which depends on every other queue's closing signal
+    const hsa_signal_value_t v = hsa_signal_wait_scacquire(g->done[slot][0], HSA_SIGNAL_CONDITION_LT, 1, WAIT_TICKS, HSA_WAIT_STATE_BLOCKED);
+    if (v >= 1) return set_error(CSIC_EHIP, "direct dispatch: submission %lld did not finish in time", (long long)ticket);
     return CSIC_OK;
 }
 
@@ -429,7 +481,9 @@ static int direct_wait(csic_frame_graph *g, int64_t ticket)
     return CSIC_OK;
 }
 
-static int direct_submit(csic_frame_graph *g, int64_t *ticket)
+// gated = stream-ordered: every queue starts with a barrier-AND packet on the slot's gate signal, which the launch
+// stream opens with hipStreamWriteValue64 once its earlier work is done.
+static int direct_submit(csic_frame_graph *g, int64_t *ticket, bool gated = false)
 {
     DirectEngine *e = g->eng;
     if (g->next_ticket - g->waited >= DIRECT_SLOTS) {           // recycle the oldest slot: the host waits for it
@@ -441,6 +495,22 @@ static int direct_submit(csic_frame_graph *g, int64_t *ticket)
     std::lock_guard<std::mutex> lk(e->mu);
     const int nq = g->branches;                                 // this graph's queues: the engine's first `nq`
     for (int j = 0; j < nq; ++j) hsa_signal_store_relaxed(g->done[slot][j], 1);
+    if (gated) {
+        hsa_signal_store_screlease(g->gate[slot], 1);
+        const uint16_t h_gate = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE);
+        for (int j = 0; j < nq; ++j) {
+            hsa_queue_t *q = e->q[j];
+            const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
+            for (uint64_t spins = 0; idx + 1 - hsa_queue_load_read_index_scacquire(q) > q->size; ++spins)
+                if (spins > 2000000000ull) return set_error(CSIC_EHIP, "direct dispatch: queue %d is not draining", j);
+            auto *bp = reinterpret_cast<hsa_barrier_and_packet_t *>(static_cast<hsa_kernel_dispatch_packet_t *>(q->base_address) + (idx & (q->size - 1)));
+            std::memset(reinterpret_cast<uint8_t *>(bp) + 4, 0, sizeof *bp - 4);
+            bp->dep_signal[0] = g->gate[slot];
+            publish(bp, h_gate, 0);
+            hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)idx);
+        }
+    }
     const uint16_t setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
     const uint16_t h_first = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                              (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE);
@@ -459,7 +529,11 @@ static int direct_submit(csic_frame_graph *g, int64_t *ticket)
             const size_t left = g->packets[j].size() - pos[j];
             const uint32_t nk = (uint32_t)(left < CHUNK ? left : CHUNK);
             const bool last = (left == nk);
-            const uint32_t total = nk + (last ? 1u : 0u);
+            // closing packets: queues 1.. end with one barrier-AND that completes their own signal; queue 0 ends with
+            // barrier-AND packet(s) that additionally DEPEND on those signals (5 dependencies per packet) and complete
+            // done[slot][0] -- the one signal the host or the launch stream waits for
+            const uint32_t nclose = (j == 0 && nq > 6) ? 2u : 1u;
+            const uint32_t total = nk + (last ? nclose : 0u);
             const uint64_t idx = hsa_queue_add_write_index_relaxed(q, total);
             // flow control: the reserved range must fit in the ring behind the read index
             for (uint64_t spins = 0; idx + total - hsa_queue_load_read_index_scacquire(q) > q->size; ++spins)
@@ -473,10 +547,15 @@ static int direct_submit(csic_frame_graph *g, int64_t *ticket)
                 publish(dst, (pos[j] + i == 0) ? h_first : h_next, setup);
             }
             if (last) {
-                auto *bp = reinterpret_cast<hsa_barrier_and_packet_t *>(&ring[(idx + nk) & mask]);
-                std::memset(reinterpret_cast<uint8_t *>(bp) + 4, 0, sizeof *bp - 4);
-                bp->completion_signal = g->done[slot][j];
-                publish(bp, h_close, 0);
+                int dep = 1;                                            // next other-queue signal queue 0 still has to await
+                for (uint32_t c = 0; c < nclose; ++c) {
+                    auto *bp = reinterpret_cast<hsa_barrier_and_packet_t *>(&ring[(idx + nk + c) & mask]);
+                    std::memset(reinterpret_cast<uint8_t *>(bp) + 4, 0, sizeof *bp - 4);
+                    if (j == 0)
+                        for (int k = 0; k < 5 && dep < nq; ++k) bp->dep_signal[k] = g->done[slot][dep++];
+                    if (c + 1 == nclose) bp->completion_signal = g->done[slot][j];
+                    publish(bp, h_close, 0);
+                }
                 closed[j] = true;
                 open -= 1;
             }
@@ -505,7 +584,9 @@ int csic_frame_graph_create_ex(csic_plan *plan, const void *const *d_in, void *c
         // Defaults from profiles/r02_small_launch.md, by the frame's data-movement floor at 8 TB/s: overlap pays the
         // more the smaller the launch; more than 4 queues/streams oversubscribe the 4 hardware queues.
         //   DIRECT  8192x8192 (25 us): 1 queue 31.3 us, 2 queues 32.1;  8192x2048 (6.3 us): 8.31 / 7.88 / 8.21 us with
-        //           1 / 2 / 4;  8192x1024 (3.1 us): 4.69 / 3.87 / 3.99;  4K sf=4 (1.3 us): 2.78 / 2.12 / 1.68
+        //           1 / 2 / 4;  8192x1024 (3.1 us): 4.69 / 3.87 / 3.99;  4K sf=4 (1.3 us): 2.78 / 2.12 / 1.78 / 1.68 with
+        //           1 / 2 / 3 / 4 -- but never 4 by default: a stream-ordered launch keeps the launch stream's queue
+        //           active as well, and a fifth active queue makes the hardware scheduler time-slice (csic.h)
         //   HIP     8192x4096: 17.1 / 15.9 us with 1 / 2 chains;  8192x1024: 5.88 / 5.15 / 4.84 with 1 / 2 / 4;  4K sf=4: 3.67 / 3.40 / 2.98
         const double floor_us = (double)plan_algorithmic_bytes(plan) / 8.0e6;
         if (backend == CSIC_FRAME_GRAPH_DIRECT) branches = floor_us >= 10.0 ? 1 : floor_us >= 2.5 ? 2 : CSIC_FRAME_GRAPH_DEFAULT_QUEUES;
@@ -542,13 +623,26 @@ int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
     CSIC_DEVICE_SCOPE(g->device);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (g->backend == CSIC_FRAME_GRAPH_DIRECT) {
-        // the library's queues are not HIP streams: order by the host (see csic.h)
-        HIP_TRY(hipStreamSynchronize(stream));
         int64_t t = 0;
-        int st = direct_submit(g, &t);
-        if (st == CSIC_OK) st = direct_wait(g, t);
-        if (st == CSIC_OK) clear_error();
-        return st;
+        if (!g->stream_ordered) {
+            // no shared signals on this runtime: order by the host
+            HIP_TRY(hipStreamSynchronize(stream));
+            int st = direct_submit(g, &t);
+            if (st == CSIC_OK) st = direct_wait(g, t);
+            if (st == CSIC_OK) clear_error();
+            return st;
+        }
+        // Asynchronous and ordered with `stream`: the queues are armed behind a gate; the stream opens it when its
+        // earlier work is done and then waits for every queue's closing packet.
+        int st = direct_submit(g, &t, true);
+        if (st != CSIC_OK) return st;
+        const int slot = (int)(t % DIRECT_SLOTS);
+        HIP_TRY(hipStreamWriteValue64(stream, g->sigmem[slot][0], 0, 0));
+        HIP_TRY(hipStreamWaitValue64(stream, g->sigmem[slot][1], 0, hipStreamWaitValueEq, ~0ull));   // queue 0's closing packet = all queues done
+        HIP_TRY(hipEventRecord(g->consumed[slot], stream));
+        g->slot_on_stream[slot] = true;
+        clear_error();
+        return CSIC_OK;
     }
     const int B = g->branches;
     if (B > 1) {
@@ -599,6 +693,12 @@ int csic_frame_graph_backend(const csic_frame_graph *g)
 {
     if (!g) return set_error(CSIC_EINVAL_NULL, "graph is NULL");
     return g->backend;
+}
+
+int csic_frame_graph_stream_ordered(const csic_frame_graph *g)
+{
+    if (!g) return set_error(CSIC_EINVAL_NULL, "graph is NULL");
+    return (g->backend == CSIC_FRAME_GRAPH_HIP || g->stream_ordered) ? 1 : 0;
 }
 
 int csic_frame_graph_destroy(csic_frame_graph *g)

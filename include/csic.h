@@ -239,17 +239,32 @@ int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *
  *                            of csic_process_device calls gives.  (ONE hipGraph with parallel branches is not
  *                            used: ROCm 7.2 replays such a graph node by node from the host, slower than a chain.)
  *   CSIC_FRAME_GRAPH_DIRECT  the same launches as pre-built AQL kernel-dispatch packets on `branches` (= queues,
- *                            default 4, max 8) user-mode HSA queues owned by the library, frame k on queue
+ *                            default up to 3, max 8) user-mode HSA queues owned by the library, frame k on queue
  *                            k % queues, WITHOUT the barrier bit HIP sets on every packet: consecutive frames
  *                            overlap like the workgroups of one big launch (cfg 5 frame: 3.65 us in a hipGraph
  *                            chain, 1.76 us here, 1.75 us in one batched launch).  These queues are NOT HIP
  *                            streams: csic_frame_graph_submit starts the work immediately -- the caller makes
  *                            the inputs ready first (e.g. by synchronising the producing stream) -- and returns
  *                            a ticket; csic_frame_graph_wait blocks the host until that submission (and all
- *                            earlier ones of this graph) has finished, outputs visible to host and device.  Up to
- *                            16 submissions may be outstanding per graph (a 17th waits for the oldest); they are
- *                            not ordered among themselves.  csic_frame_graph_launch on a DIRECT graph is the
- *                            synchronous composition  hipStreamSynchronize(hip_stream) + submit + wait.
+ *                            earlier ones of this graph) has finished, outputs visible to host and device.
+ *                            csic_frame_graph_launch(graph, hip_stream) orders the same work with a HIP stream on
+ *                            the device, asynchronously: the graph's signals are HIP "signal memory"
+ *                            (hipExtMallocWithFlags(.., hipMallocSignalMemory) -- the value word of an HSA signal,
+ *                            usable as hsa_signal_t in AQL barrier packets), so every queue starts with a gate
+ *                            packet that `hip_stream` opens with hipStreamWriteValue64 once its earlier work is
+ *                            done, and the stream then waits for every queue's closing packet with
+ *                            hipStreamWaitValue64; work enqueued on `hip_stream` afterwards sees the outputs.
+ *                            csic_frame_graph_stream_ordered() tells whether the runtime offered this (else launch
+ *                            degrades to hipStreamSynchronize + submit + wait).  A gate blocks its queues until the
+ *                            stream reaches it, so do not make that stream's earlier work depend on a LATER direct
+ *                            submission.  Up to 16 submissions/launches may be outstanding per graph (a 17th waits
+ *                            for the oldest); host-ordered submissions are not ordered among themselves.
+ *                            Queue count: the device runs 4 queues at once.  Host-ordered submissions are fastest
+ *                            on 4 (cfg 5 frame 1.71 us, 3 queues 1.78 us); a stream-ordered launch also keeps the
+ *                            launch stream's own queue busy, and with 4 + 1 active queues the hardware scheduler
+ *                            time-slices them (64 frames: 370 us instead of 157 us) -- hence the default of 3.  A
+ *                            stream-ordered launch costs 17-40 us of signal hand-offs (1-3 queues) on top of the
+ *                            host-ordered time: record many frames per graph.
  *
  * branches <= 0 selects the backend's default for the frame size (more overlap for smaller frames; measured table
  * in profiles/r02_small_launch.md).  The pointer arrays are read at creation only; the buffers they
@@ -258,7 +273,7 @@ int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *
 #define CSIC_FRAME_GRAPH_HIP    0
 #define CSIC_FRAME_GRAPH_DIRECT 1
 #define CSIC_FRAME_GRAPH_DEFAULT_BRANCHES 4   /* HIP backend, small frames (2 chains when a frame is >= 5 us of HBM time)          */
-#define CSIC_FRAME_GRAPH_DEFAULT_QUEUES   4   /* DIRECT backend, small frames (2 queues from 2.5 us, 1 queue from 10 us per frame) */
+#define CSIC_FRAME_GRAPH_DEFAULT_QUEUES   3   /* DIRECT backend, small frames (2 queues from 2.5 us, 1 queue from 10 us per frame); see below */
 typedef struct csic_frame_graph csic_frame_graph;
 int  csic_frame_graph_create(csic_plan *plan, const void *const *d_in, void *const *d_out, int32_t nframes,
                              int32_t branches, csic_frame_graph **out);
@@ -269,6 +284,7 @@ int  csic_frame_graph_submit(csic_frame_graph *graph, int64_t *ticket);         
 int  csic_frame_graph_wait(csic_frame_graph *graph, int64_t ticket);               /* DIRECT only; ticket < 0 = all */
 int  csic_frame_graph_count(const csic_frame_graph *graph, int32_t *nframes, int32_t *branches);
 int  csic_frame_graph_backend(const csic_frame_graph *graph);                      /* CSIC_FRAME_GRAPH_* or < 0 */
+int  csic_frame_graph_stream_ordered(const csic_frame_graph *graph);               /* 1: launch() is asynchronous and ordered with its stream */
 int  csic_frame_graph_destroy(csic_frame_graph *graph);
 
 /* ---- PNG files (host only, zlib) --------------------------------------------------------------------

@@ -126,6 +126,43 @@ def test_direct_graph_many_outstanding_submissions(csic, oracle):
                 g.submit()
 
 
+def test_direct_launch_is_ordered_with_its_stream_on_the_device(csic, oracle):
+    """csic_frame_graph_launch on a DIRECT graph: asynchronous, gated by and awaited on the launch stream through HIP
+    signal memory.  40 launches back to back (more than the 16 slots) on a side stream, no host synchronisation in
+    between; before each one the stream overwrites the input frames, after each one it copies the outputs away -- so a
+    gate that opened early would process the previous inputs and a wait that returned early would copy stale outputs."""
+    import torch
+    W, H, n, reps = 640, 64, 6, 40
+    cp = csic.make_c_params(W, H, 2, 0, 5, 5, 4, 2, CSQ)
+    variants = [oracle.synth_frame(n * W * H, 1000 + v) for v in range(3)]
+    pinned = [torch.from_numpy(v.view(np.int32)).pin_memory() for v in variants]
+    with csic.Plan(cp, 0) as pl:
+        opx = pl.out_width * pl.out_height
+        d_in = torch.zeros(n * W * H, dtype=torch.int32, device="cuda:0")
+        d_out = torch.zeros(n * opx, dtype=torch.int32, device="cuda:0")
+        kept = torch.zeros((reps, n * opx), dtype=torch.int32, device="cuda:0")
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with csic.FrameGraph(pl, [d_in[k * W * H:(k + 1) * W * H] for k in range(n)],
+                             [d_out[k * opx:(k + 1) * opx] for k in range(n)], backend="direct") as g:
+            if not g.stream_ordered:
+                pytest.skip("this runtime offers no HIP signal memory: launch() is host-synchronous")
+            with torch.cuda.stream(side):
+                for i in range(reps):
+                    d_in.copy_(pinned[i % 3], non_blocking=True)          # producer on the launch stream
+                    g.launch(side)                                        # returns at once
+                    kept[i].copy_(d_out, non_blocking=True)               # consumer on the launch stream
+            side.synchronize()
+            g.wait()                                                      # also valid after stream launches
+        want = []
+        for v in variants:
+            want.append(np.concatenate([oracle.process(_oparams(oracle, W, H, 2, 0, (5, 5, 4), 2), v[k * W * H:(k + 1) * W * H],
+                                                       form="closed").reshape(-1) for k in range(n)]))
+        got = kept.cpu().numpy().view(np.uint32)
+        for i in range(reps):
+            assert np.array_equal(got[i], want[i % 3]), i
+
+
 def test_direct_graph_larger_than_the_queue_rings(csic, oracle):
     """5000 tiny frames on ONE queue exceed the 4096-packet ring: the submission flows through it in chunks."""
     import torch

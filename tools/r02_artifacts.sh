@@ -20,8 +20,11 @@ bench)
   J=$OUT/bench_all_configs.jsonl; : > "$J"
   python bench.py --cpu-budget 5 --direct >> "$J" 2> "$OUT/bench.err" || exit 1
   for c in cfg5 8k_444_f1 8k_420_f1 avg_8k_420_sf2 avg_4k_420_sf4 cfg2 cfg3; do $B --config $c >> "$J" 2>> "$OUT/bench.err" || exit 1; done
-  $B --config cfg5 --per-frame-graph --graph-branches 1 --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
-  $B --config cfg5 --per-frame-graph --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  BN="python bench.py --no-cpu-baseline"
+  $BN --config cfg5 --per-frame-graph --issue hip --graph-branches 1 --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  $BN --config cfg5 --per-frame-graph --issue hip --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  $BN --config cfg5 --per-frame-graph --issue direct --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  $BN --config cfg5 --per-frame-graph --issue direct --direct-queues 4 --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config cfg2 --frames-per-step 4096 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config cfg3 --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config sq1000 --order scq --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1

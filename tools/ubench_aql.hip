@@ -10,6 +10,7 @@
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 #include <hsa/hsa_ven_amd_loader.h>
+#include <hsa/amd_hsa_signal.h>
 
 #include <algorithm>
 #include <chrono>
@@ -323,6 +324,86 @@ int main(int argc, char **argv)
     timeline("1 queue, no barrier bit", 1, false);
     timeline("2 queues, no barrier bit", 2, false);
     timeline("4 queues, no barrier bit", 4, false);
+
+    // ---- stream-ordered probe: can a HIP stream gate and await work on our queues?  HIP's "signal memory"
+    // (hipExtMallocWithFlags(.., hipMallocSignalMemory)) is the value word of an HSA signal the runtime created; the
+    // amd_signal_t it belongs to starts 8 bytes earlier (amd_hsa_signal.h), which makes it usable as an hsa_signal_t in
+    // AQL barrier packets while hipStreamWriteValue64 / hipStreamWaitValue64 operate on the same word.
+    {
+        int can = 0;
+        CK(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0));
+        uint64_t *sv[1 + MAXQ] = {};
+        bool ok = can != 0;
+        const int Q = 4;
+        for (int i = 0; ok && i < 1 + Q; ++i) {
+            if (hipExtMallocWithFlags(reinterpret_cast<void **>(&sv[i]), 8, hipMallocSignalMemory) != hipSuccess) { ok = false; break; }
+            const int64_t kind = reinterpret_cast<volatile int64_t *>(sv[i])[-1];
+            if (kind != AMD_SIGNAL_KIND_USER || ((reinterpret_cast<uintptr_t>(sv[i]) - 8) & 63)) { printf("signal memory %d: kind %lld, not an amd_signal_t\n", i, (long long)kind); ok = false; }
+        }
+        printf("stream-ordered probe: CanUseStreamWaitValue=%d, signal memory %s\n", can, ok ? "looks like amd_signal_t.value" : "unusable");
+        if (ok) {
+            auto handle = [&](int i) { hsa_signal_t h; h.handle = reinterpret_cast<uint64_t>(sv[i]) - 8; return h; };
+            hipStream_t st;
+            CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            for (int rep = 0; rep < 3; ++rep) {
+                // producer on the HIP stream: clear, then regenerate the inputs; our kernels must not start before it is done
+                CK(hipMemsetAsync(din, 0, ipx * 4 * N, st));
+                CK(hipMemsetAsync(dout, 0, opx * 4 * N, st));
+                for (int i = 0; i < 1 + Q; ++i) hsa_signal_store_screlease(handle(i), 1);
+                // our queues: [barrier-AND on S] kernels (no barrier bit) [closing barrier-AND -> D_j]
+                uint64_t idx[MAXQ]; int cnt[MAXQ], pos[MAXQ] = {0};
+                for (int j = 0; j < Q; ++j) { cnt[j] = N / Q + (j < N % Q ? 1 : 0); idx[j] = hsa_queue_add_write_index_relaxed(qs[j], cnt[j] + 2); }
+                for (int j = 0; j < Q; ++j) {
+                    auto *rg = static_cast<hsa_kernel_dispatch_packet_t *>(qs[j]->base_address);
+                    auto *bp = reinterpret_cast<hsa_barrier_and_packet_t *>(&rg[idx[j] & (qs[j]->size - 1)]);
+                    memset(reinterpret_cast<uint8_t *>(bp) + 4, 0, sizeof *bp - 4);
+                    bp->dep_signal[0] = handle(0);
+                    const uint16_t bh = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                        (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE);
+                    __atomic_store_n(reinterpret_cast<uint32_t *>(bp), uint32_t(bh), __ATOMIC_RELEASE);
+                }
+                for (int k = 0; k < N; ++k) {
+                    const int j = k % Q;
+                    auto *rg = static_cast<hsa_kernel_dispatch_packet_t *>(qs[j]->base_address);
+                    hsa_kernel_dispatch_packet_t *pk = &rg[(idx[j] + 1 + pos[j]) & (qs[j]->size - 1)];
+                    pk->workgroup_size_x = d[k].block.x; pk->workgroup_size_y = d[k].block.y; pk->workgroup_size_z = d[k].block.z;
+                    pk->reserved0 = 0;
+                    pk->grid_size_x = d[k].grid.x * d[k].block.x; pk->grid_size_y = d[k].grid.y * d[k].block.y; pk->grid_size_z = d[k].grid.z * d[k].block.z;
+                    pk->private_segment_size = 0; pk->group_segment_size = 0;
+                    pk->kernel_object = f.kernel_object;
+                    pk->kernarg_address = dk + k * kstride;
+                    pk->reserved2 = 0;
+                    pk->completion_signal.handle = 0;
+                    const int first = pos[j] == 0;
+                    const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (first << HSA_PACKET_HEADER_BARRIER) |
+                                            ((first ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE) << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE);
+                    __atomic_store_n(reinterpret_cast<uint32_t *>(pk), header | (uint32_t(3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS) << 16), __ATOMIC_RELEASE);
+                    ++pos[j];
+                }
+                for (int j = 0; j < Q; ++j) {
+                    auto *rg = static_cast<hsa_kernel_dispatch_packet_t *>(qs[j]->base_address);
+                    auto *bp = reinterpret_cast<hsa_barrier_and_packet_t *>(&rg[(idx[j] + 1 + cnt[j]) & (qs[j]->size - 1)]);
+                    memset(reinterpret_cast<uint8_t *>(bp) + 4, 0, sizeof *bp - 4);
+                    bp->completion_signal = handle(1 + j);
+                    const uint16_t bh = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                        (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+                    __atomic_store_n(reinterpret_cast<uint32_t *>(bp), uint32_t(bh), __ATOMIC_RELEASE);
+                }
+                for (int j = 0; j < Q; ++j) hsa_signal_store_screlease(qs[j]->doorbell_signal, idx[j] + cnt[j] + 1);
+                // the queues are armed and blocked on S; only now does the stream produce the inputs and open the gate
+                csic_synth_frame_device(din, (int64_t)ipx * N, 0, 20250629u, st);
+                CK(hipStreamWriteValue64(st, sv[0], 0, 0));
+                for (int j = 0; j < Q; ++j) CK(hipStreamWaitValue64(st, sv[1 + j], 0, hipStreamWaitValueEq, ~0ull));
+                uint64_t sum = 0;
+                csic_checksum_device(dout, (int64_t)opx * N, &sum, st);      // ordered behind the waits; synchronises the stream
+                printf("  rep %d: gate by hipStreamWriteValue64, await by hipStreamWaitValue64: output %s\n", rep,
+                       sum == ref_sum ? "bit-exact vs HIP launch (ordering held both ways)" : "MISMATCH");
+                fflush(stdout);
+            }
+            CK(hipStreamDestroy(st));
+        }
+        for (int i = 0; i < 1 + MAXQ; ++i) if (sv[i]) (void)hipFree(sv[i]);
+    }
 
     for (int Q : {1, 2, 3, 4, 6, 8}) report_mq(Q, rounds);
     for (int Q : {1, 2, 4, 8}) report_mq(Q, 1);          // one 64-frame "graph launch" at a time, host waits in between
