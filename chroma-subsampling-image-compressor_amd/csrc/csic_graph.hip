@@ -637,7 +637,13 @@ int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
         int st = direct_submit(g, &t, true);
         if (st != CSIC_OK) return st;
         const int slot = (int)(t % DIRECT_SLOTS);
-        HIP_TRY(hipStreamWriteValue64(stream, g->sigmem[slot][0], 0, 0));
+        hipError_t e = hipStreamWriteValue64(stream, g->sigmem[slot][0], 0, 0);
+        if (e != hipSuccess) {
+            // the queues are armed behind the gate: never leave them blocked -- open it from the host (the work then
+            // runs unordered with the stream, which the error return tells the caller) and fall back to a host wait
+            hsa_signal_store_screlease(g->gate[slot], 0);
+            return set_error(CSIC_EHIP, "hipStreamWriteValue64 failed: %s", hipGetErrorString(e));
+        }
         HIP_TRY(hipStreamWaitValue64(stream, g->sigmem[slot][1], 0, hipStreamWaitValueEq, ~0ull));   // queue 0's closing packet = all queues done
         HIP_TRY(hipEventRecord(g->consumed[slot], stream));
         g->slot_on_stream[slot] = true;

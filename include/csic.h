@@ -266,6 +266,8 @@ int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *
  *                            stream-ordered launch costs 17-40 us of signal hand-offs (1-3 queues) on top of the
  *                            host-ordered time: record many frames per graph.
  *
+ * A graph, like a plan, is not thread-safe (one thread at a time per graph; different graphs may be used from different
+ * threads, the library serialises their access to its queues).
  * branches <= 0 selects the backend's default for the frame size (more overlap for smaller frames; measured table
  * in profiles/r02_small_launch.md).  The pointer arrays are read at creation only; the buffers they
  * name must stay valid for as long as the graph is launched.  csic_frame_graph_create == _create_ex with

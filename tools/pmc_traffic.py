@@ -71,6 +71,8 @@ def main():
             plan_kernel = json.load(open(bench_json))["config"]["kernel"]
         except Exception:
             pass
+    hpath = os.path.join(src, "source_sha256.txt")       # written by tools/profile.sh on the box that ran the profile
+    profiled_hash = open(hpath).read().strip() if os.path.exists(hpath) else kernel_source_sha256(ROOT)
     tpath = os.path.join(dst, "pmc_traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
     for k, v in summary["bench"].items():
@@ -82,7 +84,7 @@ def main():
             "plan_kernel": plan_kernel, "rocprof_kernel": k, "tag": tag,
             # the counters describe exactly these sources (the .so that was profiled travels with them to the GPU
             # box); bench.py reports the traffic only while the checkout still hashes to this value
-            "source_sha256": kernel_source_sha256(ROOT),
+            "source_sha256": profiled_hash,
             "hbm_read_bytes_per_launch": round(rd), "hbm_write_bytes_per_launch": round(wr),
             "hbm_bytes_per_launch": round(rd + wr),
             "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB units); read side x2 per "
