@@ -126,6 +126,8 @@ public:
         check(csic_process_device(plan(f), d_in, d_out, hip_stream));
     }
     const char *kernelName(PixelFormat f = PixelFormat::ARGB8888) { return csic_plan_kernel_name(plan(f)); }
+    // the plan behind process(): what FrameGraph records launches of (owned by this object)
+    csic_plan *nativePlan(PixelFormat f = PixelFormat::ARGB8888) { return plan(f); }
 
 private:
     csic_plan *plan(PixelFormat f)
@@ -148,6 +150,34 @@ private:
     csic_plan *plan_[2] = {nullptr, nullptr};
     int32_t out_w_ = 0, out_h_ = 0;
     int device_;
+};
+
+// Pre-recorded per-frame launches (csic_frame_graph_*): frames in separate device buffers, recorded once and replayed
+// so that small launches overlap.  HIP = hipGraph chains ordered with the caller's stream; DIRECT = AQL packets without
+// barrier bits on the library's own queues -- launch(stream) orders them with a HIP stream on the device, submit()/wait()
+// by the host.  The reference processes one image at a time (ImageCompressorTopApp.scala:53-68).
+enum class FrameGraphBackend : int32_t { HIP = CSIC_FRAME_GRAPH_HIP, DIRECT = CSIC_FRAME_GRAPH_DIRECT };
+
+class FrameGraph {
+public:
+    FrameGraph(csic_plan *plan, const std::vector<const void *> &d_in, const std::vector<void *> &d_out,
+               FrameGraphBackend backend = FrameGraphBackend::HIP, int branches = 0)
+    {
+        if (d_in.size() != d_out.size() || d_in.empty())
+            throw IllegalArgumentException(CSIC_EINVAL_SIZE, "need as many output as input frames (> 0)");
+        check(csic_frame_graph_create_ex(plan, d_in.data(), d_out.data(), (int32_t)d_in.size(), branches, (int32_t)backend, &g_));
+    }
+    FrameGraph(const FrameGraph &) = delete;
+    FrameGraph &operator=(const FrameGraph &) = delete;
+    ~FrameGraph() { csic_frame_graph_destroy(g_); }
+    void launch(void *hip_stream) { check(csic_frame_graph_launch(g_, hip_stream)); }
+    int64_t submit() { int64_t t = 0; check(csic_frame_graph_submit(g_, &t)); return t; }
+    void wait(int64_t ticket = -1) { check(csic_frame_graph_wait(g_, ticket)); }
+    bool streamOrdered() const { return csic_frame_graph_stream_ordered(g_) == 1; }
+    int branches() const { int32_t n = 0, b = 0; csic_frame_graph_count(g_, &n, &b); return b; }
+
+private:
+    csic_frame_graph *g_ = nullptr;
 };
 
 class ImageProcessor : public ImageCompressorTop {

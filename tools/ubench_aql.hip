@@ -266,10 +266,17 @@ int main(int argc, char **argv)
     // ---- dispatch timeline from the CP's own timestamps (hsa_amd_profiling_get_dispatch_time): one 64-frame round per
     // configuration with a completion signal on every packet.  rocprofv3's kernel trace cannot show this: its queue
     // interception serialises the dispatches (max 1 kernel in flight, 6-8 us per frame under the profiler).
+    // dedicated queues, profiling enabled before their first packet (toggling it on a used queue returned zero
+    // timestamps on some boxes)
+    hsa_queue_t *tq[4];
+    for (int j = 0; j < 4; ++j) {
+        HK(hsa_queue_create(f.agent, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &tq[j]));
+        HK(hsa_amd_profiling_set_profiler_enabled(tq[j], 1));
+    }
     auto timeline = [&](const char *name, int Q, bool barrier_bit) {
+        hsa_queue_t **qs = tq;                                           // (shadows the benchmark queues)
         std::vector<hsa_signal_t> sig(N);
         for (int k = 0; k < N; ++k) HK(hsa_signal_create(1, 0, nullptr, &sig[k]));
-        for (int j = 0; j < Q; ++j) HK(hsa_amd_profiling_set_profiler_enabled(qs[j], 1));
         for (int rep = 0; rep < 3; ++rep) {                              // the last repetition is reported
             for (int k = 0; k < N; ++k) hsa_signal_store_relaxed(sig[k], 1);
             uint64_t idx[MAXQ]; int cnt[MAXQ], pos[MAXQ] = {0};
@@ -317,13 +324,13 @@ int main(int argc, char **argv)
         printf("timeline %-28s span %7.2f us = %5.2f us/frame; mean kernel %5.2f us; kernels in flight: mean %.2f, max %d\n", name,
                (t1 - t0) * us, (t1 - t0) * us / N, sum * us / N, area / double(t1 - t0), mx);
         fflush(stdout);
-        for (int j = 0; j < Q; ++j) HK(hsa_amd_profiling_set_profiler_enabled(qs[j], 0));
         for (int k = 0; k < N; ++k) hsa_signal_destroy(sig[k]);
     };
     timeline("1 queue, barrier bit", 1, true);
     timeline("1 queue, no barrier bit", 1, false);
     timeline("2 queues, no barrier bit", 2, false);
     timeline("4 queues, no barrier bit", 4, false);
+    for (int j = 0; j < 4; ++j) hsa_queue_destroy(tq[j]);
 
     // ---- stream-ordered probe: can a HIP stream gate and await work on our queues?  HIP's "signal memory"
     // (hipExtMallocWithFlags(.., hipMallocSignalMemory)) is the value word of an HSA signal the runtime created; the
