@@ -188,6 +188,25 @@ def test_compute_fails_loudly_without_a_gpu():
     assert ei.value.status == N.ENODEVICE and "no CPU fallback" in str(ei.value)
 
 
+def test_frame_graph_entry_points_validate_without_a_gpu():
+    """The frame-graph ABI rejects bad arguments before it touches a device (and never falls back to anything)."""
+    L = N.lib()
+    h = C.c_void_p()
+    arr = (C.c_void_p * 1)(None)
+    assert L.csic_frame_graph_create(None, arr, arr, 1, 1, C.byref(h)) == N.EINVAL_NULL
+    assert L.csic_frame_graph_create_ex(None, arr, arr, 1, 1, N.FRAME_GRAPH_DIRECT, C.byref(h)) == N.EINVAL_NULL
+    assert L.csic_frame_graph_create_ex(None, arr, arr, 1, 1, N.FRAME_GRAPH_DIRECT, None) == N.EINVAL_NULL
+    assert not h.value
+    assert L.csic_frame_graph_launch(None, None) == N.EINVAL_NULL
+    assert L.csic_frame_graph_submit(None, None) == N.EINVAL_NULL
+    assert L.csic_frame_graph_wait(None, -1) == N.EINVAL_NULL
+    assert L.csic_frame_graph_count(None, None, None) == N.EINVAL_NULL
+    assert L.csic_frame_graph_backend(None) == N.EINVAL_NULL
+    assert L.csic_frame_graph_stream_ordered(None) == N.EINVAL_NULL
+    assert L.csic_frame_graph_destroy(None) == N.OK
+    assert "graph is NULL" in L.csic_last_error().decode() or L.csic_last_error().decode() == ""
+
+
 def test_product_package_never_touches_the_oracle():
     """No include, import, load or call of anything under oracle/ from the product tree (comments may cite
     the oracle as the normative statement of the AVG extension)."""

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential run: the HIP path (through the C ABI) against the CPU oracle on fresh seeds.
     python tools/fuzz_gpu.py [seconds] [seed]
-Covers every kernel family, both samplings, both input formats, tuning knobs, odd shapes and batches.
+Covers every kernel family, both samplings, both input formats, tuning knobs, odd shapes and batches, and -- for one
+case in three -- the pre-recorded launch paths: the same frames through a frame graph (csic_frame_graph_*), HIP chains or
+direct dispatch, ordered by the host (submit/wait) or with a stream (launch), random branch/queue counts.
 This is a TOOL for hunting corner cases on the GPU box; the fixed-seed versions live in tests/."""
 import itertools
 import os
@@ -10,6 +12,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch
 import csic_amd as csic
 from oracle import oracle as orc
 
@@ -58,5 +61,32 @@ while time.time() < t_end:
                       f"rounding={rounding} fmt={fmt} avg={avg} ycc_in={ycc_in} knob={knob}={val} first_bad={bad[0].tolist()} "
                       f"count={len(bad)}")
                 sys.exit(1)
+        if rng.random() < 0.34 and not ycc_in:
+            # the same frame, 1-5 copies with different contents, through a pre-recorded frame graph
+            for knob in (N.TUNE_NONTEMPORAL, N.TUNE_NO_VECTOR, N.TUNE_VARIANT, N.TUNE_FORCE_GENERIC):
+                pl.tune(knob, 1 if knob == N.TUNE_NONTEMPORAL else 0)
+            nf = int(rng.integers(1, 6))
+            frames = [frame] + [rng.integers(0, 1 << 32, W * H, dtype=np.uint32) for _ in range(nf - 1)]
+            wants = [want] + [orc.process(op_, fr, "avg" if avg else "closed") for fr in frames[1:]]
+            d_ins = [torch.from_numpy(fr.view(np.int32)).cuda() for fr in frames]
+            d_outs = [torch.zeros(pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0") for _ in range(nf)]
+            backend = "direct" if rng.random() < 0.6 else "hip"
+            br = [None, 1, 2, 3, 4, 8][int(rng.integers(0, 6))]
+            torch.cuda.synchronize()
+            with csic.FrameGraph(pl, d_ins, d_outs, branches=br, backend=backend) as g:
+                how = "launch"
+                if backend == "direct" and rng.random() < 0.5:
+                    how = "submit"
+                    g.wait(g.submit())
+                else:
+                    g.launch()
+                torch.cuda.synchronize()
+                families["graph:" + backend + ":" + how] = families.get("graph:" + backend + ":" + how, 0) + 1
+            for k in range(nf):
+                got = d_outs[k].cpu().numpy().view(np.uint32).reshape(wants[k].shape)
+                if not np.array_equal(got, wants[k]):
+                    print(f"MISMATCH (frame graph {backend}/{how}, branches={br}, frame {k} of {nf}) seed={seed} case={n} {pl.kernel_name} "
+                          f"W={W} H={H} a={a} b={b} bits={bits} f={f} op={op} rounding={rounding} fmt={fmt} avg={avg}")
+                    sys.exit(1)
     n += 1
 print(f"fuzz ok: seed {seed}, {n} cases, launches per family {families}")
