@@ -157,7 +157,8 @@ class Workload:
         order = SCQ if args.order == "scq" else CSQ
         gparams = csic.make_c_params(W, gH, a, b, *bits, f, order, sampling=sampling)
         r0, nr, o0, on = (C.c_int32() for _ in range(4))
-        N.check(lib.csic_stripe_rows(C.byref(gparams), world, rank, C.byref(r0), C.byref(nr), C.byref(o0), C.byref(on)))
+        parts, part = (args.stripe_of, 0) if (args.stripe_of > 1 and world == 1) else (world, rank)
+        N.check(lib.csic_stripe_rows(C.byref(gparams), parts, part, C.byref(r0), C.byref(nr), C.byref(o0), C.byref(on)))
         self.row0, self.stripe_rows = r0.value, nr.value
         if self.stripe_rows == 0:
             raise SystemExit(f"rank {rank}: empty stripe ({gH} rows over {world} ranks)")
@@ -191,6 +192,7 @@ class Workload:
         self.out_ptrs = [C.c_void_p(t.data_ptr()) for t in self.outs]
         self.graphs = []
         self.step_graph = None
+        self.rem_graph = None
         self.world = world
         self.issue = issue
         self._build_step()
@@ -240,6 +242,11 @@ class Workload:
             self.step_graph = csic.FrameGraph(self.plan, self.ins, self.outs, backend=backend,
                                               branches=(args.direct_queues if backend == "direct" else args.step_chains) or None)
             self.launch_desc = describe(self.step_graph, f"one launch per step; {nring} consecutive steps (the ring)")
+            # the ragged end of the K timed steps (K % nring) comes from a second, shorter graph instead of a Python loop
+            rem = args.steps % nring
+            if rem:
+                self.rem_graph = csic.FrameGraph(self.plan, self.ins[:rem], self.outs[:rem], backend=backend,
+                                                 branches=self.step_graph.branches)
 
     def run_steps(self, first, count):
         """Issues steps first .. first+count-1 (asynchronous).  Returns the OR of the launch statuses."""
@@ -250,10 +257,14 @@ class Workload:
                 st |= step(i)
             return st
         nring, i, end = self.nring, first, first + count
-        while i < end:                                      # whole-ring graph replays, eager launches for the ragged ends
+        rem = self.rem_graph.nframes if self.rem_graph is not None else 0
+        while i < end:                                      # whole-ring graph replays; ragged ends: the short graph, else eager
             if i % nring == 0 and end - i >= nring:
                 self.step_graph.launch(self.stream)
                 i += nring
+            elif rem and i % nring == 0 and end - i == rem:
+                self.rem_graph.launch(self.stream)
+                i += rem
             else:
                 st |= self.step(i)
                 i += 1
@@ -264,6 +275,8 @@ class Workload:
             g.close()
         if self.step_graph is not None:
             self.step_graph.close()
+        if self.rem_graph is not None:
+            self.rem_graph.close()
         self.plan.close()
         self.ins = self.outs = None
         self.torch.cuda.empty_cache()
@@ -396,8 +409,9 @@ def main(argv=None):
                     help="how the steps reach the GPU (see Workload): serial = one eager launch per step on the launch stream; hip / "
                          "direct = the same launches replayed from a frame graph (CSIC_FRAME_GRAPH_HIP chains / CSIC_FRAME_GRAPH_DIRECT "
                          "AQL packets without barrier bits), both ordered with the launch stream and timed by the same HIP events.  "
-                         "auto: N=1 serial (the roofline contract: the profiler's per-kernel average must describe the timed launches), "
-                         "N>1 direct (a 3 us stripe launch needs pre-built launches; falls back to hip if the runtime refuses)")
+                         "auto: N=1 serial (the roofline contract: the profiler's per-kernel average must describe the timed launches); "
+                         "N>1 pre-recorded launches -- hip while a step is >= 5 us of HBM time (N <= 4 for cfg4), direct below (N = 8; "
+                         "falls back to hip if the runtime refuses)")
     ap.add_argument("--step-chains", type=int, default=0,
                     help="issue hip: hipGraph chains among consecutive steps (0 = library default for the stripe size, 1 = single-stream order)")
     ap.add_argument("--direct-queues", type=int, default=0,
@@ -412,6 +426,10 @@ def main(argv=None):
                          "streams so that one frame's ramp-up overlaps the previous frame's drain.  Per-kernel durations "
                          "then overlap and rocprofv3's averages no longer equal the launch period, so this mode is for "
                          "quantifying headroom only.")
+    ap.add_argument("--stripe-of", type=int, default=0,
+                    help="N=1 only: process rank 0's stripe of an N-way strong split (8192 x 8192/N) exactly as a rank of "
+                         "`--gpus N` would (same stripe, same issue mode, same ring), to measure on one GPU what each rank of the "
+                         "N-GPU run does; `value` is then that ONE rank's rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = ap.parse_args(argv)
@@ -458,7 +476,12 @@ def main(argv=None):
     if args.issue != "auto":
         issue = args.issue
     else:
-        issue = "serial" if world == 1 else "direct"
+        # N > 1: pre-recorded launches.  Measured per stripe size (profiles/r02_bench_stripe_of.jsonl): from 8192x2048 up
+        # the HIP backend's two chains are as fast as direct dispatch behind its stream hand-offs (8.12 vs 8.20 us, 15.80 vs
+        # 16.36 us); at 8192x1024 direct dispatch wins (4.06 vs 4.40 us).  The split point is 5 us of HBM time per step.
+        parts = args.stripe_of if (world == 1 and args.stripe_of > 1) else world
+        step_floor_us = 4.0 * W * (-(-H // f) + -(-W // f) * -(-H // f) / W) / parts / (HBM_PEAK_GBS * 1e3)
+        issue = "serial" if parts == 1 else ("direct" if step_floor_us < 5.0 else "hip")
     issue_note = None
     try:
         wl = Workload(args, csic, torch, dev, dev_index, world, rank, headline_mode, issue)
@@ -548,6 +571,13 @@ def main(argv=None):
                 sides["hip_streams" if other_issue == "hip" else "direct_dispatch"] = side(headline_mode, other_issue)
             except csic.CsicRuntimeError as exc:
                 sides["direct_dispatch"] = {"unavailable": str(exc)}
+    elif args.stripe_of > 1 and can_graph and not args.no_side:
+        other_issue = "hip" if issue == "direct" else "direct"
+        try:
+            sides["hip_streams" if other_issue == "hip" else "direct_dispatch"] = side(headline_mode, other_issue)
+        except csic.CsicRuntimeError as exc:
+            sides["direct_dispatch"] = {"unavailable": str(exc)}
+        sides["serial_launches"] = side(headline_mode, "serial")
     elif args.direct and can_graph and issue != "direct":
         try:
             sides["direct_dispatch"] = side(headline_mode, "direct")
@@ -572,7 +602,9 @@ def main(argv=None):
                             f"order {order_txt}, {head['fps']} frame(s)/step, FLOOR_HW",
                 "stripe_rows_per_gpu": head["stripe_rows"], "global_rows": head["global_rows"], "ring_frames": head["nring"],
                 "prewarm_ms": args.prewarm_ms,
-                "parallelism": f"row-stripe x{world}, no data-path collective",
+                "parallelism": (f"row-stripe x{world}, no data-path collective" if args.stripe_of <= 1 else
+                                f"ONE RANK'S SHARE of a row-stripe x{args.stripe_of} run, measured alone on one GPU (--stripe-of): `value` is "
+                                "this rank's input pixels per second, the N-GPU value would be N times it if every rank does the same"),
                 "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else " (rehearsal: ranks share one GPU)")) if world > 1 else "none (single process)",
                 "world_size_formed": formed,
                 "kernel": head["kernel"],

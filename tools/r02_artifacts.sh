@@ -6,6 +6,7 @@
 #   small    : tools/small_launch.py, tools/ubench_overlap, tools/ubench_aql, frame-graph kernel traces
 #   host     : tools/host_io.py
 #   sweep    : tools/sweep.py, tools/ubench
+#   stripes  : bench.py --stripe-of 2/4/8 -> bench_stripe_of.jsonl
 set -o pipefail
 STAGE=${1:-bench}
 TAG=${2:-r02}
@@ -63,6 +64,19 @@ sweep)
   tail -3 "$OUT/sweep.md"
   ( cd /tmp && timeout -k 10 600 $ROOT/tools/ubench > "$OUT/ubench.log" 2>&1 ) || exit 1
   tail -3 "$OUT/ubench.log"
+  ;;
+stripes)
+  # what ONE rank of the N-GPU strong-scaling run does, measured alone on this GPU (bench.py --stripe-of N)
+  J=$OUT/bench_stripe_of.jsonl; : > "$J"
+  for n in 2 4 8; do python bench.py --stripe-of $n --no-cpu-baseline >> "$J" 2>> "$OUT/bench.err" || exit 1; done
+  python - "$J" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    r = json.loads(l)
+    print(r["config"]["stripe_rows_per_gpu"], r["config"]["issue"], r["ms_per_step"], r["roofline"]["frac"],
+          {k: r[k]["ms_per_step"] for k in ("hip_streams", "direct_dispatch", "serial_launches", "direct_host_ordered") if k in r},
+          (r.get("direct_dispatch") or {}).get("host_ordered", {}).get("ms_per_step"))
+PY
   ;;
 *) echo "unknown stage $STAGE"; exit 2 ;;
 esac
