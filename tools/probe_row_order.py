@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """tools/probe_row_order.py -- does the ORDER in which k_dec's blocks visit the rows matter (DRAM bank aliasing of rows at a
 power-of-two stride)?  CSIC_TUNE_ROW_MUL = m makes block row i process output row (i * m) mod Ho.  8192x8192, 4:2:0, one frame
-per launch over a ring of 32 frames (the headline's conditions) and f = 2 / 4 / 8; outputs checked against m = 1."""
+per launch over a ring of 32 frames (the headline's conditions) and f = 2 / 4 / 8; outputs checked against m = 1.
+
+Result (profiles/r02_probe_row_order.log): in-order is the best order at every f (f = 2: 32.52 us in order, 32.94-43.99 us
+permuted), so the knob was NOT kept in the library: apply tools/patches/row_order_knob.patch (adds CSIC_TUNE_ROW_MUL = 6) to
+re-run this probe."""
 import ctypes as C, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,7 +27,7 @@ for f in (2, 8, 4):
     outs = [torch.empty(opx, dtype=torch.int32, device=dev) for _ in range(nring)]
     ref = None
     for mul in (1, 3, 7, 17, 37, 101, 257, 1021, 2049, 1):
-        plan.tune(N.TUNE_ROW_MUL, mul)
+        plan.tune(getattr(N, 'TUNE_ROW_MUL', 6), mul)
         def step(i):
             return lib.csic_process_device(plan._h, C.c_void_p(ins[i % nring].data_ptr()), C.c_void_p(outs[i % nring].data_ptr()), sh)
         t_end = time.perf_counter() + 0.3
