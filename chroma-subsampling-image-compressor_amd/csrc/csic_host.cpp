@@ -101,6 +101,14 @@ int derive_geometry(const csic_params *p, Geometry *g)
     return CSIC_OK;
 }
 
+void magic_div(uint32_t d, uint32_t *m, uint32_t *k)
+{
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    *k = 31 + l;
+    *m = (uint32_t)(((1ull << *k) + d - 1) / d);
+}
+
 } // namespace csic
 
 using namespace csic;

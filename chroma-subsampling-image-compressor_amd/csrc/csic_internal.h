@@ -22,4 +22,10 @@ int  set_error(int status, const char *fmt, ...) __attribute__((format(printf, 2
 void clear_error();
 int  derive_geometry(const csic_params *p, Geometry *g);   // validates first
 
+// Exact unsigned division by a run-time constant without a divide (k_generic's stream-index arithmetic): for
+// 1 <= d < 2^31 and every n < 2^31,  n / d == (uint64(n) * m) >> k  with  k = 31 + ceil(log2 d),  m = ceil(2^k / d) < 2^32.
+// (Error term e = m*d - 2^k < d <= 2^ceil(log2 d), and n * e < 2^31 * 2^ceil(log2 d) = 2^k.)  Host side, csic_host.cpp;
+// checked against the hardware divide over edge cases and random pairs in tests/cpp/host_sanitize.cpp.
+void magic_div(uint32_t d, uint32_t *m, uint32_t *k);
+
 } // namespace csic

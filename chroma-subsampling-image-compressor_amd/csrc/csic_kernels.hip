@@ -774,17 +774,6 @@ static void select(csic_plan *pl)
 
 static int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-// Exact unsigned division by a run-time constant without a divide: for 1 <= d < 2^31 and every n < 2^31,
-//   n / d == (uint64(n) * m) >> k   with  k = 31 + ceil(log2 d),  m = ceil(2^k / d)  (m < 2^32).
-// (Error term e = m*d - 2^k < d <= 2^ceil(log2 d), and n * e < 2^31 * 2^ceil(log2 d) = 2^k.)
-static void magic_div(uint32_t d, uint32_t *m, uint32_t *k)
-{
-    uint32_t l = 0;
-    while ((1ull << l) < d) ++l;
-    *k = 31 + l;
-    *m = (uint32_t)(((1ull << *k) + d - 1) / d);
-}
-
 int prepare_launch(const csic_plan *pl, const void *d_in, void *d_out, int nframes, int32_t in_pitch, int32_t out_pitch,
                    LaunchDesc *d)
 {

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "csic.h"
+#include "csic_internal.h"
 
 static uint32_t rng_state = 12345;
 static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 17; rng_state ^= rng_state << 5; return rng_state; }
@@ -38,8 +39,44 @@ static void resign(std::vector<unsigned char> &png)      // recompute every chun
     }
 }
 
+// magic_div must reproduce the hardware divide for every dividend below 2^31
+static int check_magic_div()
+{
+    const uint32_t edges[] = {1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 125, 250, 255, 256, 257, 500, 960, 1000, 1023, 1024, 1025,
+                              1920, 3840, 4095, 4096, 4097, 7680, 8191, 8192, 8193, 65535, 65536, 65537, 1u << 20, (1u << 20) + 1, 16777215,
+                              16777216, 16777217, (1u << 30) - 1, 1u << 30, (1u << 30) + 1, 2147483646u, 2147483647u};
+    long n_checked = 0;
+    auto one = [&](uint32_t d) -> bool {
+        uint32_t m = 0, k = 0;
+        csic::magic_div(d, &m, &k);
+        if (k < 31 || k > 62) return false;
+        auto ok = [&](uint32_t n) { ++n_checked; return (uint32_t)(((uint64_t)n * m) >> k) == n / d; };
+        for (uint32_t n : edges) if (!ok(n)) return false;
+        for (uint64_t q = 0; q < 6; ++q)                                  // multiples of d and their neighbours
+            for (int64_t off = -2; off <= 2; ++off) {
+                const int64_t n = (int64_t)(q * 357913941ull % (2147483648ull / d + 1)) * d + off;
+                if (n >= 0 && n < 2147483648ll && !ok((uint32_t)n)) return false;
+            }
+        const int64_t top = (int64_t)(2147483647u / d) * d;              // the largest multiple below 2^31
+        for (int64_t off = -2; off <= 2; ++off)
+            if (top + off >= 0 && top + off < 2147483648ll && !ok((uint32_t)(top + off))) return false;
+        for (int i = 0; i < 64; ++i) if (!ok(rnd() & 0x7FFFFFFFu)) return false;
+        return true;
+    };
+    for (uint32_t d : edges) if (!one(d)) { std::printf("magic_div wrong for d = %u\n", d); return 1; }
+    for (int i = 0; i < 200000; ++i) {
+        uint32_t d = rnd() & 0x7FFFFFFFu;
+        if (i & 1) d >>= (rnd() % 31);                                   // small divisors matter most (frame widths)
+        if (d == 0) d = 1;
+        if (!one(d)) { std::printf("magic_div wrong for d = %u\n", d); return 1; }
+    }
+    std::printf("magic_div: %ld quotients checked\n", n_checked);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (check_magic_div()) return 1;
     // ---- validation / geometry / stripes over a grid of good and bad parameters
     long checked = 0;
     for (int W : {-1, 0, 1, 5, 16, 8192, 65536}) for (int H : {0, 1, 3, 4096, 40000})
