@@ -624,8 +624,14 @@ int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (g->backend == CSIC_FRAME_GRAPH_DIRECT) {
         int64_t t = 0;
-        if (!g->stream_ordered) {
-            // no shared signals on this runtime: order by the host
+        // A gated submission sits in the rings until the stream opens the gate -- which it is only asked to do after the
+        // submission has been written.  One that does not fit in a ring (gate + packets + closing packets) can therefore
+        // not be armed ahead of time; it takes the host-ordered path.
+        size_t longest = 0;
+        for (int j = 0; j < g->branches; ++j) longest = g->packets[j].size() > longest ? g->packets[j].size() : longest;
+        const bool fits = longest + 3 <= QUEUE_PACKETS;
+        if (!g->stream_ordered || !fits) {
+            // no shared signals on this runtime (or a graph larger than the rings): order by the host
             HIP_TRY(hipStreamSynchronize(stream));
             int st = direct_submit(g, &t);
             if (st == CSIC_OK) st = direct_wait(g, t);

@@ -38,3 +38,18 @@ def test_cpp_host_layer_requires_and_png(tmp_path):
 @pytest.mark.gpu
 def test_cpp_host_layer_kats_and_integration_flow_on_gpu(tmp_path):
     _run("gpu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_frame_graph_c_abi_from_native_hip_host_code():
+    """tests/cpp/graph_test.hip: csic_frame_graph_* from C++ with the HIP runtime (hipcc), both backends, producer and
+    consumer on the launch stream, no Python between the host code and the C ABI."""
+    src = os.path.join(ROOT, "tests", "cpp", "graph_test.hip")
+    exe = os.path.join(ROOT, "tests", "cpp", "graph_test")
+    lib = os.path.join(PKG, "libcsic_hip.so")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), src,
+                               "-L" + PKG, "-lcsic_hip", "-Wl,-rpath," + PKG, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+    assert "backend DIRECT" in r.stdout and "backend HIP" in r.stdout

@@ -177,6 +177,11 @@ def test_direct_graph_larger_than_the_queue_rings(csic, oracle):
         with csic.FrameGraph(pl, [d_in[k * W * H:(k + 1) * W * H] for k in range(n)],
                              [d_out[k * opx:(k + 1) * opx] for k in range(n)], branches=1, backend="direct") as g:
             g.wait(g.submit())
+            first = d_out.clone()
+            d_out.zero_()
+            g.launch()                   # cannot be armed behind a gate (does not fit in the ring): host-ordered path
+            torch.cuda.synchronize()
+            assert torch.equal(first, d_out)
         got = d_out.cpu().numpy().view(np.uint32).reshape(n, opx)
         for k in range(0, n, 97):
             want = oracle.process(_oparams(oracle, W, H, 2, 0, (8, 8, 8), 2), host[k * W * H:(k + 1) * W * H], form="closed")

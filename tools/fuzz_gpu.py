@@ -23,6 +23,7 @@ ORDERS = list(itertools.permutations((1, 2, 3)))
 MODES = [(4, 4), (2, 2), (2, 0), (1, 1), (4, 0), (1, 0)]
 N = csic._native
 t_end, n, families = time.time() + budget, 0, {}
+t_progress = time.time() + 60.0
 while time.time() < t_end:
     kind = rng.random()
     if kind < 0.15:
@@ -89,4 +90,7 @@ while time.time() < t_end:
                           f"W={W} H={H} a={a} b={b} bits={bits} f={f} op={op} rounding={rounding} fmt={fmt} avg={avg}")
                     sys.exit(1)
     n += 1
+    if time.time() >= t_progress:                        # a progress line a minute (long runs must not look hung)
+        print(f"... {n} cases so far, no mismatch", flush=True)
+        t_progress = time.time() + 60.0
 print(f"fuzz ok: seed {seed}, {n} cases, launches per family {families}")
