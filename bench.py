@@ -183,8 +183,15 @@ class Workload:
         self.nring = max(2, min(ring_cap, (args.ring_mib << 20) // max(step_in_bytes, 1)))
         self.stream = torch.cuda.current_stream(dev)
         self.sh = C.c_void_p(self.stream.cuda_stream)
-        self.ins = [torch.empty(self.in_px * fps, dtype=torch.int32, device=dev) for _ in range(self.nring)]
-        self.outs = [torch.empty(self.out_px * fps, dtype=torch.int32, device=dev) for _ in range(self.nring)]
+        # --pitch-pad: rows padded by that many pixels in HBM (csic_process_pitched_device); the frame and the bytes the
+        # kernel moves are the same, only the row addresses change (profiles/r02_probe_pitch.log)
+        self.pad = args.pitch_pad if (args.pitch_pad > 0 and issue == "serial" and fps == 1) else 0
+        self.in_pitch = W + self.pad
+        self.out_pitch = self.plan.out_width + (self.pad // f if self.pad else 0)
+        n_in = self.stripe_rows * self.in_pitch if self.pad else self.in_px * fps
+        n_out = self.plan.out_height * self.out_pitch if self.pad else self.out_px * fps
+        self.ins = [torch.empty(n_in, dtype=torch.int32, device=dev) for _ in range(self.nring)]
+        self.outs = [torch.empty(n_out, dtype=torch.int32, device=dev) for _ in range(self.nring)]
         for k, t in enumerate(self.ins):
             first = (k * world + rank) * self.in_px * fps + self.row0 * W
             N.check(lib.csic_synth_frame_device(C.c_void_p(t.data_ptr()), t.numel(), first, 20250629, self.sh))
@@ -223,6 +230,13 @@ class Workload:
             def step(i):
                 self.graphs[i % nring].launch(self.stream)
                 return 0
+        elif fps == 1 and self.pad:
+            self.launch_desc = (f"one launch per step (csic_process_pitched_device, rows padded by {self.pad} px: pitch "
+                                f"{self.in_pitch} / {self.out_pitch} px), eager, one stream")
+            ip, op = self.in_pitch, self.out_pitch
+
+            def step(i):
+                return lib.csic_process_pitched_device(ph, in_ptrs[i % nring], ip, out_ptrs[i % nring], op, 1, sh)
         elif fps == 1:
             self.launch_desc = "one launch per step (csic_process_device), eager, one stream"
 
@@ -426,6 +440,11 @@ def main(argv=None):
                          "streams so that one frame's ramp-up overlaps the previous frame's drain.  Per-kernel durations "
                          "then overlap and rocprofv3's averages no longer equal the launch period, so this mode is for "
                          "quantifying headroom only.")
+    ap.add_argument("--pitch-pad", type=int, default=0,
+                    help="EXPERIMENT (serial issue, one frame per step): keep the frames in HBM with their rows padded by this many "
+                         "pixels (a multiple of 32 keeps rows 128-byte aligned) and launch through csic_process_pitched_device.  "
+                         "Packed rows are the default and the headline; 8192-wide rows sit at a power-of-two pitch, which costs "
+                         "DRAM efficiency (profiles/r02_probe_pitch.log)")
     ap.add_argument("--stripe-of", type=int, default=0,
                     help="N=1 only: process rank 0's stripe of an N-way strong split (8192 x 8192/N) exactly as a rank of "
                          "`--gpus N` would (same stripe, same issue mode, same ring), to measure on one GPU what each rank of the "
@@ -586,7 +605,8 @@ def main(argv=None):
 
     if rank == 0:
         traffic, traffic_note = load_traffic(args.config, head["kernel"], world)
-        if args.frames_per_step > 0 or args.order != "csq" or args.per_frame_graph or args.block_threads or args.variant >= 0 or args.no_vector:
+        if args.frames_per_step > 0 or args.order != "csq" or args.per_frame_graph or args.block_threads or args.variant >= 0 or args.no_vector \
+                or args.pitch_pad:
             traffic, traffic_note = None, "PMC entries are for the default launch of each config only"
         lpf, out_px, in_px = head["lpf"], head["out_px"], head["in_px"]
         order_txt = "chroma->spatial->quant" if args.order == "csq" else "spatial->chroma->quant"

@@ -814,10 +814,18 @@ int prepare_launch(const csic_plan *pl, const void *d_in, void *d_out, int nfram
     magic_div((uint32_t)g.W, &a.mW, &a.kW);
     magic_div((uint32_t)g.Wo, &a.mWo, &a.kWo);
 
-    // threads per block: 256 by default; CSIC_TUNE_BLOCK_THREADS (64 / 128 / 256) for A/B on small launches
-    const int tpb = (pl->block_threads == 64 || pl->block_threads == 128) ? pl->block_threads : 256;
+    // Threads per block.  256 by default; k_dec takes two-wave blocks (128 threads) for a single frame of >= 64 MB whose rows
+    // tile into full waves at that width: measured on one-frame-per-launch streams (profiles/r02_probe_block_shapes.log)
+    // 8192x8192 f=2 32.48 -> 31.89 us, 16384x4096 32.56 -> 31.98, 8192x4096 17.44 -> 17.27, 6144x6144 19.38 -> 19.18,
+    // 8192x8192 f=4 15.52 -> 15.37; no gain below ~64 MB (8192x2048: 9.88 / 9.88), none for batched launches, and a loss
+    // where 128 lanes do not divide the row into full waves (7680x4320: 17.29 -> 17.93).  CSIC_TUNE_BLOCK_THREADS overrides.
     const int rows = (fam == FAM_F1X4) ? g.H : (fam == FAM_AVG) ? g.H / (g.f > g.v ? g.f : g.v) : g.Ho;
     const int lanes_x = (units + kpl - 1) / kpl;
+    int tpb = 256;
+    if (pl->block_threads == 64 || pl->block_threads == 128 || pl->block_threads == 256) tpb = pl->block_threads;
+    else if (fam == FAM_DEC && nframes == 1 && units % kpl == 0 && lanes_x % 128 == 0 &&
+             4ll * ((int64_t)g.W * g.Ho + (int64_t)g.Wo * g.Ho) >= (64ll << 20))
+        tpb = 128;
     int bx = pow2_ceil(lanes_x);
     if (bx > tpb) bx = tpb;
     if (bx < 1) bx = 1;

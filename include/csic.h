@@ -175,12 +175,12 @@ const char *csic_plan_kernel_name(const csic_plan *plan);
  *   CSIC_TUNE_FORCE_GENERIC : 1 = always use the one-thread-per-pixel generic kernel
  *   CSIC_TUNE_NONTEMPORAL   : 1 (default) = non-temporal loads/stores for the frame stream, 0 = cached
  *   CSIC_TUNE_NO_VECTOR     : 1 = never use the 16-byte-per-lane kernels
- *   CSIC_TUNE_BLOCK_THREADS : threads per block, 64 / 128 / 256 (0 = default 256) */
+ *   CSIC_TUNE_BLOCK_THREADS : threads per block, 64 / 128 / 256 (0 = the library's choice) */
 #define CSIC_TUNE_VARIANT        1
 #define CSIC_TUNE_FORCE_GENERIC  2
 #define CSIC_TUNE_NONTEMPORAL    3
 #define CSIC_TUNE_NO_VECTOR      4   /* 1 = 4-byte accesses only (what unaligned pointers get automatically) */
-#define CSIC_TUNE_BLOCK_THREADS  5   /* 0 (default) = 256 threads per block; 64 or 128 = smaller blocks      */
+#define CSIC_TUNE_BLOCK_THREADS  5   /* 0 (default) = the library's choice (256; 128 for a large single frame); 64 / 128 / 256 = forced */
 int  csic_plan_tune(csic_plan *plan, int32_t knob, int32_t value);
 
 /* One frame, device-resident: d_in holds width*height input pixels, d_out receives

@@ -36,11 +36,11 @@ def small_launch_md(src, dst, tag):
                 fh.write(f"; {d['batched'][2]}: **{d['batched'][0]} µs per frame ({100 * d['batched'][1]:.1f} %)**")
             fh.write("\n\n| backend | block threads | b1 | b2 | b3 | b4 | b6 | b8 |\n|---|---|---|---|---|---|---|---|\n")
             for be in ("hip", "direct"):
-                for thr in (256, 128, 64):
+                for thr in (0, 256, 128, 64):
                     cells = [d.get((be, thr, b)) for b in (1, 2, 3, 4, 6, 8)]
                     if not any(cells):
                         continue
-                    fh.write(f"| {be} | {thr} | " + " | ".join(f"{c[0]:.2f} ({100 * c[1]:.0f} %)" if c else "—" for c in cells) + " |\n")
+                    fh.write(f"| {be} | {thr if thr else 'default'} | " + " | ".join(f"{c[0]:.2f} ({100 * c[1]:.0f} %)" if c else "—" for c in cells) + " |\n")
             fh.write("\n")
 
 

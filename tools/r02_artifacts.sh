@@ -40,7 +40,7 @@ profile)
   ;;
 small)
   rm -f "$OUT/small_launch.jsonl"
-  timeout -k 10 600 python tools/small_launch.py --threads 256,128 --out "$OUT/small_launch.jsonl" > "$OUT/small_launch.log" 2>&1 || exit 1
+  timeout -k 10 600 python tools/small_launch.py --threads 0,128 --out "$OUT/small_launch.jsonl" > "$OUT/small_launch.log" 2>&1 || exit 1
   ( cd /tmp
     timeout -k 10 150 $ROOT/tools/ubench_overlap cfg5 30 256 > "$OUT/ubench_overlap_cfg5.log" 2>&1 || exit 1
     timeout -k 10 150 $ROOT/tools/ubench_overlap stripe8 30 256 > "$OUT/ubench_overlap_stripe8.log" 2>&1 || exit 1

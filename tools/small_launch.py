@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "small_launch.jsonl"))
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--branches", default="1,2,3,4,6,8")
-    ap.add_argument("--threads", default="256,128,64")
+    ap.add_argument("--threads", default="0,128", help="CSIC_TUNE_BLOCK_THREADS values; 0 = the library's default choice")
     ap.add_argument("--backends", default="hip,direct")
     args = ap.parse_args()
 
