@@ -154,12 +154,12 @@ def main():
     if "stripes" in what:
         # strong-scaling stripes of the cfg 4 frame: 8192 x (8192 / N) for N = 1, 2, 4, 8 (and 16)
         for Hs, ring in ((8192, 8), (4096, 16), (2048, 32), (1024, 64), (512, 64)):
-            run_case(f"cfg4 stripe 1/{8192 // Hs}", 8192, Hs, 2, 0, (8, 8, 8), 2, ring, 64, brs, thr if Hs <= 2048 else [256])
+            run_case(f"cfg4 stripe 1/{8192 // Hs}", 8192, Hs, 2, 0, (8, 8, 8), 2, ring, 64, brs, thr if Hs <= 2048 else thr[:1])
     if "cfg5" in what:
         run_case("cfg5 frame", 3840, 2160, 2, 0, (3, 3, 2), 4, 64, 64, brs, thr)
     if "cfg23" in what:
-        run_case("cfg3 frame", 512, 512, 2, 0, (3, 3, 2), 2, 1024, 256, brs, [256])
-        run_case("cfg2 frame", 128, 128, 2, 2, (3, 3, 2), 1, 4096, 256, brs, [256])
+        run_case("cfg3 frame", 512, 512, 2, 0, (3, 3, 2), 2, 1024, 256, brs, thr[:1])
+        run_case("cfg2 frame", 128, 128, 2, 2, (3, 3, 2), 1, 4096, 256, brs, thr[:1])
     fout.close()
 
 
