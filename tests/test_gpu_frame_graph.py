@@ -257,3 +257,44 @@ def test_two_ranks_sharing_the_gpu_halo_exchange_with_cuda_rows():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert '"all_bit_exact": true' in r.stdout
     assert r.stdout.count('"case": "halo"') == 10 and '"bit_exact_all_ranks": false' not in r.stdout
+
+
+def test_distinct_graphs_from_distinct_threads_share_the_engine(csic, oracle):
+    """The library serialises access to its queues: two threads, each with its own plan and direct graph (one host-ordered,
+    one stream-ordered on its own stream), hammering the same engine; plus a third graph created and destroyed meanwhile."""
+    import threading
+    import torch
+    results, errors = {}, []
+
+    def worker(tid, W, H, f, use_stream):
+        try:
+            torch.cuda.set_device(0)
+            cp = csic.make_c_params(W, H, 2, 0, 4, 4, 4, f, CSQ)
+            host = [oracle.synth_frame(W * H, 17 * tid + k) for k in range(5)]
+            with csic.Plan(cp, 0) as pl:
+                d_ins = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
+                d_outs = [torch.zeros(pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0") for _ in host]
+                st = torch.cuda.Stream()
+                torch.cuda.synchronize()
+                with csic.FrameGraph(pl, d_ins, d_outs, backend="direct") as g:
+                    for _ in range(60):
+                        if use_stream:
+                            g.launch(st)
+                        else:
+                            g.wait(g.submit())
+                    st.synchronize()
+                    g.wait()
+                got = [t.cpu().numpy().view(np.uint32) for t in d_outs]
+            want = [oracle.process(_oparams(oracle, W, H, 2, 0, (4, 4, 4), f), h, form="closed").reshape(-1) for h in host]
+            results[tid] = all(np.array_equal(a, b) for a, b in zip(got, want))
+        except Exception as exc:                       # noqa: BLE001 -- surfaced below
+            errors.append((tid, repr(exc)))
+
+    ts = [threading.Thread(target=worker, args=(0, 512, 64, 2, False)), threading.Thread(target=worker, args=(1, 384, 48, 1, True)),
+          threading.Thread(target=worker, args=(2, 256, 32, 4, True))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert results == {0: True, 1: True, 2: True}
