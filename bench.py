@@ -209,10 +209,13 @@ class Workload:
         args, lib, ph, nring, sh = self.args, self.lib, self.plan._h, self.nring, self.sh
         in_ptrs, out_ptrs, fps = self.in_ptrs, self.out_ptrs, self.fps
         import csic_amd as csic
-        backend = "direct" if self.issue == "direct" else "hip"
+        backend = {"direct": "direct", "fused": "fused"}.get(self.issue, "hip")
         branches = (args.direct_queues if backend == "direct" else args.graph_branches) or None
 
         def describe(g, what):
+            if g.backend == "fused":
+                return (f"{what} as ONE kernel launch over a device-resident frame-pointer table (CSIC_FRAME_GRAPH_FUSED; frames in "
+                        "separate buffers, not per-frame launches)")
             if g.backend == "direct":
                 return (f"{what} replayed from a frame graph, CSIC_FRAME_GRAPH_DIRECT: pre-built AQL packets without barrier bits on "
                         f"{g.branches} user-mode queue(s), " + ("gated by and awaited on the launch stream (HIP signal memory)"
@@ -419,10 +422,11 @@ def main(argv=None):
     ap.add_argument("--graph-branches", type=int, default=0,
                     help="--per-frame-graph: number of independent chains in the frame graph (0 = library default, "
                          "1 = strictly serial, what capturing a loop on one stream gives)")
-    ap.add_argument("--issue", default="auto", choices=["auto", "serial", "hip", "direct"],
+    ap.add_argument("--issue", default="auto", choices=["auto", "serial", "hip", "direct", "fused"],
                     help="how the steps reach the GPU (see Workload): serial = one eager launch per step on the launch stream; hip / "
                          "direct = the same launches replayed from a frame graph (CSIC_FRAME_GRAPH_HIP chains / CSIC_FRAME_GRAPH_DIRECT "
-                         "AQL packets without barrier bits), both ordered with the launch stream and timed by the same HIP events.  "
+                         "AQL packets without barrier bits), both ordered with the launch stream and timed by the same HIP events; fused = "
+                         "the recorded frames as ONE launch over a pointer table (not per-frame launches; for --per-frame-graph comparisons).  "
                          "auto: N=1 serial (the roofline contract: the profiler's per-kernel average must describe the timed launches); "
                          "N>1 pre-recorded launches -- hip while a step is >= 5 us of HBM time (N <= 4 for cfg4), direct below (N = 8; "
                          "falls back to hip if the runtime refuses)")

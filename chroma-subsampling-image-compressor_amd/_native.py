@@ -20,7 +20,7 @@ OP_NOOP, OP_SPATIAL, OP_QUANT, OP_CHROMA = 0, 1, 2, 3
 ROUND_FLOOR_HW, ROUND_TRUNC_SW = 0, 1
 FMT_ARGB8888, FMT_YCBCR888X = 0, 1
 TUNE_VARIANT, TUNE_FORCE_GENERIC, TUNE_NONTEMPORAL, TUNE_NO_VECTOR, TUNE_BLOCK_THREADS = 1, 2, 3, 4, 5
-FRAME_GRAPH_HIP, FRAME_GRAPH_DIRECT = 0, 1
+FRAME_GRAPH_HIP, FRAME_GRAPH_DIRECT, FRAME_GRAPH_FUSED = 0, 1, 2
 FRAME_GRAPH_DEFAULT_BRANCHES, FRAME_GRAPH_DEFAULT_QUEUES = 4, 3
 PIPELINE_STAGED, PIPELINE_ZERO_COPY = 0, 1
 

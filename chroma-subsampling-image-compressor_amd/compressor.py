@@ -134,9 +134,12 @@ class FrameGraph:
     backend "direct": AQL packets without barrier bits on the library's own user-mode queues (`branches` =
     queues); submit() starts immediately and returns a ticket, wait() blocks the host; launch(stream) is
     asynchronous and ordered with the stream on the device when `stream_ordered` (HIP signal memory shared with
-    the queues), else the synchronous composition stream-sync + submit + wait."""
+    the queues), else the synchronous composition stream-sync + submit + wait.
+    backend "fused": not per-frame launches -- one kernel launch over all frames through a device-resident pointer
+    table (frames in separate buffers at the speed of the contiguous batched launch); launch(stream) is an ordinary
+    asynchronous launch."""
 
-    BACKENDS = {"hip": N.FRAME_GRAPH_HIP, "direct": N.FRAME_GRAPH_DIRECT}
+    BACKENDS = {"hip": N.FRAME_GRAPH_HIP, "direct": N.FRAME_GRAPH_DIRECT, "fused": N.FRAME_GRAPH_FUSED}
 
     def __init__(self, plan: Plan, d_ins, d_outs, branches=None, backend: str = "hip"):
         n = len(d_ins)

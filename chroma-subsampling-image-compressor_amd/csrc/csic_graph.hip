@@ -14,7 +14,10 @@
 //     AQL packets, no barrier bit, 4 queues   1.76 us   74 %                           <- CSIC_FRAME_GRAPH_DIRECT
 //     one batched launch of all 64 frames     1.75 us   74 %   (needs contiguous frames)
 //
-// Two backends therefore:
+// Three backends therefore (the third needs no overlap at all):
+//  * CSIC_FRAME_GRAPH_FUSED: ONE launch over all frames -- the kernels read their frame base from a device-resident
+//    pointer table indexed by grid z, so separate buffers cost nothing against the contiguous batched launch.  Not
+//    "per-frame launches", but the fastest way to run N frames of one plan in stream order.
 //  * CSIC_FRAME_GRAPH_HIP: `branches` hipGraph CHAINS (explicit kernel nodes from prepare_launch(), so a node is
 //    bit for bit the eager launch), chain 0 replayed on the caller's stream and the others on internal streams,
 //    forked and joined with events -- fully ordered with the caller's stream, works under stream capture rules of
@@ -289,6 +292,9 @@ struct csic_frame_graph {
     std::vector<hipStream_t> streams;           // streams[i] serves chain i (streams[0] unused); borrowed from the device's pool
     std::vector<hipEvent_t> joins;
     hipEvent_t fork = nullptr;
+    // FUSED backend: device-resident pointer tables + one launch descriptor per 65535 frames
+    void *d_tables = nullptr;
+    std::vector<LaunchDesc> fused;
     // DIRECT backend
     DirectEngine *eng = nullptr;
     void *d_kernarg = nullptr;
@@ -317,6 +323,7 @@ static void graph_free(csic_frame_graph *g)
     if (g->fork) (void)hipEventDestroy(g->fork);
     for (auto s : g->streams) if (s) (void)hipStreamSynchronize(s);        // pooled: not destroyed here
     if (g->d_kernarg) (void)hipFree(g->d_kernarg);
+    if (g->d_tables) (void)hipFree(g->d_tables);
     if (g->have_signals && !g->stream_ordered)
         for (int s = 0; s < DIRECT_SLOTS; ++s)
             for (int j = 0; j < MAX_QUEUES; ++j)
@@ -364,6 +371,30 @@ static int build_hip(csic_frame_graph *g, csic_plan *plan, const void *const *d_
         }
     }
     if (B > 1) HIP_TRY(hipEventCreateWithFlags(&g->fork, hipEventDisableTiming));
+    return CSIC_OK;
+}
+
+// FUSED: the frames of ONE plan need not be contiguous to share a launch -- the kernels take their frame base from a
+// device-resident pointer table indexed by grid z.  One ordinary kernel launch on the caller's stream: asynchronous, ordered,
+// capturable, and as fast as the contiguous batched launch.
+static int build_fused(csic_frame_graph *g, csic_plan *plan, const void *const *d_in, void *const *d_out)
+{
+    const int n = g->nframes;
+    uintptr_t align_bits = 0;
+    for (int k = 0; k < n; ++k) align_bits |= (uintptr_t)d_in[k] | (uintptr_t)d_out[k];
+    const size_t bytes = (size_t)n * sizeof(void *);
+    HIP_TRY(hipMalloc(&g->d_tables, 2 * bytes));
+    HIP_TRY(hipMemcpy(g->d_tables, d_in, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(static_cast<uint8_t *>(g->d_tables) + bytes, d_out, bytes, hipMemcpyHostToDevice));
+    const void *const *tin = static_cast<const void *const *>(g->d_tables);
+    void *const *tout = reinterpret_cast<void *const *>(static_cast<uint8_t *>(g->d_tables) + bytes);
+    for (int f0 = 0; f0 < n; f0 += 65535) {                       // grid z limit
+        const int nz = (n - f0 < 65535) ? n - f0 : 65535;
+        LaunchDesc d;
+        const int st = prepare_launch_table(plan, tin + f0, tout + f0, align_bits, nz, &d);
+        if (st != CSIC_OK) return st;
+        try { g->fused.push_back(d); } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
+    }
     return CSIC_OK;
 }
 
@@ -577,8 +608,9 @@ int csic_frame_graph_create_ex(csic_plan *plan, const void *const *d_in, void *c
     *out = nullptr;
     if (!plan || !d_in || !d_out) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
     if (nframes < 1 || nframes > 65536) return set_error(CSIC_EINVAL_SIZE, "nframes must be in 1..65536. Got %d", nframes);
-    if (backend != CSIC_FRAME_GRAPH_HIP && backend != CSIC_FRAME_GRAPH_DIRECT)
+    if (backend != CSIC_FRAME_GRAPH_HIP && backend != CSIC_FRAME_GRAPH_DIRECT && backend != CSIC_FRAME_GRAPH_FUSED)
         return set_error(CSIC_EINVAL_SIZE, "unknown frame-graph backend %d", backend);
+    if (backend == CSIC_FRAME_GRAPH_FUSED) branches = 1;          // one launch: nothing to overlap with
     const int cap = backend == CSIC_FRAME_GRAPH_DIRECT ? MAX_QUEUES : 16;
     if (branches <= 0) {
         // Defaults from profiles/r02_small_launch.md, by the frame's data-movement floor at 8 TB/s: overlap pays the
@@ -604,7 +636,8 @@ int csic_frame_graph_create_ex(csic_plan *plan, const void *const *d_in, void *c
     g->backend = backend;
     g->nframes = nframes;
     g->branches = branches;
-    const int st = backend == CSIC_FRAME_GRAPH_DIRECT ? build_direct(g, plan, d_in, d_out) : build_hip(g, plan, d_in, d_out);
+    const int st = backend == CSIC_FRAME_GRAPH_DIRECT ? build_direct(g, plan, d_in, d_out)
+                 : backend == CSIC_FRAME_GRAPH_FUSED ? build_fused(g, plan, d_in, d_out) : build_hip(g, plan, d_in, d_out);
     if (st != CSIC_OK) { graph_free(g); return st; }
     *out = g;
     clear_error();
@@ -622,6 +655,14 @@ int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
     if (!g) return set_error(CSIC_EINVAL_NULL, "graph is NULL");
     CSIC_DEVICE_SCOPE(g->device);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (g->backend == CSIC_FRAME_GRAPH_FUSED) {
+        for (const LaunchDesc &d : g->fused) {
+            const int st = enqueue(d, stream);
+            if (st != CSIC_OK) return st;
+        }
+        clear_error();
+        return CSIC_OK;
+    }
     if (g->backend == CSIC_FRAME_GRAPH_DIRECT) {
         int64_t t = 0;
         // A gated submission sits in the rings until the stream opens the gate -- which it is only asked to do after the
@@ -710,7 +751,7 @@ int csic_frame_graph_backend(const csic_frame_graph *g)
 int csic_frame_graph_stream_ordered(const csic_frame_graph *g)
 {
     if (!g) return set_error(CSIC_EINVAL_NULL, "graph is NULL");
-    return (g->backend == CSIC_FRAME_GRAPH_HIP || g->stream_ordered) ? 1 : 0;
+    return (g->backend != CSIC_FRAME_GRAPH_DIRECT || g->stream_ordered) ? 1 : 0;
 }
 
 int csic_frame_graph_destroy(csic_frame_graph *g)

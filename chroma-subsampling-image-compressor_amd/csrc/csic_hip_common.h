@@ -43,6 +43,8 @@ struct KArgs {
     int32_t bdx, bdy, row_step;         // block width/height and gridDim.y * bdy, passed explicitly (see pin_args)
     int32_t ip, op;                     // row pitch of the input / output frame in pixels (>= W / Wo; == when packed)
     uint32_t mW, mWo, kW, kWo;          // k_generic: exact n / W and n / Wo for n < 2^31 as (n * m) >> k (see magic_div)
+    const uint32_t *const *in_tab;      // frame-table mode (CSIC_FRAME_GRAPH_FUSED): frame z reads in_tab[z] and writes out_tab[z];
+    uint32_t *const *out_tab;           //   null = frames lie back to back behind `in` / `out`
 };
 
 using KernelFn = void (*)(KArgs);
@@ -58,6 +60,10 @@ struct LaunchDesc {
 // limit) and fills *d.  Does not touch the device.
 int prepare_launch(const csic_plan *pl, const void *d_in, void *d_out, int nframes, int32_t in_pitch, int32_t out_pitch,
                    LaunchDesc *d);
+// The same for `nframes` frames in SEPARATE buffers named by device-resident pointer tables (one launch, frame index on
+// grid z): `align_bits` is the bitwise OR of every frame pointer in the tables (the vector kernels need all of them 16-byte aligned).
+int prepare_launch_table(const csic_plan *pl, const void *const *d_in_tab, void *const *d_out_tab, uintptr_t align_bits, int nframes,
+                         LaunchDesc *d);
 int enqueue(const LaunchDesc &d, hipStream_t stream);
 int launch_on_stream(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream);
 int plan_device(const csic_plan *pl);

@@ -50,7 +50,18 @@ __device__ __forceinline__ void pin_args(const KArgs &a)
 {
     asm volatile("" ::"s"(a.in), "s"(a.out), "s"(a.W), "s"(a.H), "s"(a.Wo), "s"(a.Ho), "s"(a.last_sample_col));
     asm volatile("" ::"s"(a.my), "s"(a.mcb), "s"(a.mcr), "s"(a.in_frame_px), "s"(a.out_frame_px), "s"(a.bdx),
-                 "s"(a.bdy), "s"(a.row_step), "s"(a.ip), "s"(a.op));
+                 "s"(a.bdy), "s"(a.row_step), "s"(a.ip), "s"(a.op), "s"(a.in_tab), "s"(a.out_tab));
+}
+
+// Base of the frame this block works on (grid z = frame): consecutive frames behind a.in / a.out, or -- frame-table mode --
+// whatever the device-resident tables name (one wave-uniform scalar load).
+__device__ __forceinline__ const uint32_t *frame_in(const KArgs &a)
+{
+    return a.in_tab ? a.in_tab[blockIdx.z] : a.in + (int64_t)blockIdx.z * a.in_frame_px;
+}
+__device__ __forceinline__ uint32_t *frame_out(const KArgs &a)
+{
+    return a.out_tab ? a.out_tab[blockIdx.z] : a.out + (int64_t)blockIdx.z * a.out_frame_px;
 }
 
 enum { R_FLOOR = CSIC_ROUND_FLOOR_HW, R_TRUNC = CSIC_ROUND_TRUNC_SW };
@@ -190,8 +201,8 @@ __global__ void __launch_bounds__(256) k_f1x4(KArgs a)
     const int W4 = a.W >> 2;
     const int x4 = blockIdx.x * a.bdx + threadIdx.x;
     if (x4 >= W4) return;
-    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
-    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const uint32_t *in = frame_in(a);
+    uint32_t *out = frame_out(a);
     const int row_step = a.row_step;
     for (int row = blockIdx.y * a.bdy + threadIdx.y; row < a.H; row += row_step) {
         const int64_t base = (int64_t)row * a.ip + 4 * x4;
@@ -310,8 +321,8 @@ __global__ void __launch_bounds__(256) k_dec(KArgs a)
     const int bx = a.bdx;
     const int cbase = blockIdx.x * (bx * K);
     const int co0 = cbase + threadIdx.x;
-    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
-    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const uint32_t *in = frame_in(a);
+    uint32_t *out = frame_out(a);
     const int row_step = a.row_step;
     const int ro0 = blockIdx.y * a.bdy + threadIdx.y;
     // two separate row loops (the condition is uniform over the block) so that the fast path keeps
@@ -335,8 +346,8 @@ __global__ void __launch_bounds__(256) k_dec2v(KArgs a)
     const int nx = a.Wo / OPL;                          // lanes per row (W % 8 == 0 -> exact)
     const int x = blockIdx.x * a.bdx + threadIdx.x;
     if (x >= nx) return;
-    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
-    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const uint32_t *in = frame_in(a);
+    uint32_t *out = frame_out(a);
     const int row_step = a.row_step;
     for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += row_step) {
         const uint32_t *rowp = in + (int64_t)(ro * 2) * a.ip + (int64_t)x * (OPL * 2);
@@ -464,8 +475,8 @@ __global__ void __launch_bounds__(256) k_avg(KArgs a)
     const int W4 = a.W >> 2;
     const int x0 = blockIdx.x * (a.bdx * TILES) + threadIdx.x;
     if (x0 >= W4) return;
-    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
-    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const uint32_t *in = frame_in(a);
+    uint32_t *out = frame_out(a);
     const int ntr = a.H / TH;
     for (int tr = blockIdx.y * a.bdy + threadIdx.y; tr < ntr; tr += a.row_step) {
         u32x4 p[TILES][TH];
@@ -490,8 +501,8 @@ __global__ void __launch_bounds__(256) k_avg_generic(KArgs a)
     pin_args(a);
     const int co = blockIdx.x * a.bdx + threadIdx.x;
     if (co >= a.Wo) return;
-    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
-    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const uint32_t *in = frame_in(a);
+    uint32_t *out = frame_out(a);
     const int h = a.hmask + 1, v = a.vmask + 1, f = a.f;
     const int nlog = (h == 4 ? 2 : h == 2 ? 1 : 0) + (v == 2 ? 1 : 0);
     const int flog2 = 2 * a.sc_shift;
@@ -531,8 +542,8 @@ __global__ void __launch_bounds__(256) k_generic(KArgs a)
     pin_args(a);
     const int co = blockIdx.x * a.bdx + threadIdx.x;
     if (co >= a.Wo) return;
-    const uint32_t *in = a.in + (int64_t)blockIdx.z * a.in_frame_px;
-    uint32_t *out = a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    const uint32_t *in = frame_in(a);
+    uint32_t *out = frame_out(a);
     const int row_step = a.row_step;
     for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += row_step) {
         const int64_t y_idx = (int64_t)(ro * a.f) * a.ip + co * a.f;
@@ -774,11 +785,10 @@ static void select(csic_plan *pl)
 
 static int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-int prepare_launch(const csic_plan *pl, const void *d_in, void *d_out, int nframes, int32_t in_pitch, int32_t out_pitch,
-                   LaunchDesc *d)
+// Resolves kernel, grid and arguments for `nframes` frames (<= 65535, the grid z limit) whose base pointers OR to
+// `align_bits`; the callers below fill in where the frames are.
+static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes, int32_t in_pitch, int32_t out_pitch, LaunchDesc *d)
 {
-    if (!pl) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
-    if (!d_in || !d_out) return set_error(CSIC_EINVAL_NULL, "device buffer is NULL");
     if (nframes <= 0 || nframes > 65535)
         return set_error(CSIC_EINVAL_SIZE, "nframes per launch must be in 1..65535. Got %d", nframes);
     const Geometry &g = pl->g;
@@ -791,7 +801,7 @@ int prepare_launch(const csic_plan *pl, const void *d_in, void *d_out, int nfram
     if (ip < g.W || op < g.Wo)
         return set_error(CSIC_EINVAL_SIZE, "row pitch (%d, %d px) smaller than the frame width (%d, %d px)", ip, op, g.W, g.Wo);
     const bool vec = (fam == FAM_F1X4 || fam == FAM_DEC2V1 || fam == FAM_DEC2V2 || fam == FAM_AVG);
-    if (vec && (((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15u) || ((ip | op) & 3))) {
+    if (vec && ((align_bits & 15u) || ((ip | op) & 3))) {
         csic_plan tmp = *pl;
         tmp.no_vec = 1;
         select(&tmp);
@@ -799,8 +809,7 @@ int prepare_launch(const csic_plan *pl, const void *d_in, void *d_out, int nfram
     }
 
     KArgs &a = d->args;
-    a.in = static_cast<const uint32_t *>(d_in);
-    a.out = static_cast<uint32_t *>(d_out);
+    a.in = nullptr; a.out = nullptr; a.in_tab = nullptr; a.out_tab = nullptr;
     a.W = g.W; a.H = g.H; a.Wo = g.Wo; a.Ho = g.Ho;
     a.last_sample_col = g.last_sample_col;
     a.my = g.mask_y; a.mcb = g.mask_cb; a.mcr = g.mask_cr;
@@ -850,6 +859,30 @@ int prepare_launch(const csic_plan *pl, const void *d_in, void *d_out, int nfram
     a.bdx = bx; a.bdy = by; a.row_step = (int32_t)gy * by;
     d->grid = dim3(gx, gy, (unsigned)nframes);
     d->fn = fn;
+    return CSIC_OK;
+}
+
+int prepare_launch(const csic_plan *pl, const void *d_in, void *d_out, int nframes, int32_t in_pitch, int32_t out_pitch,
+                   LaunchDesc *d)
+{
+    if (!pl) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
+    if (!d_in || !d_out) return set_error(CSIC_EINVAL_NULL, "device buffer is NULL");
+    const int st = prepare_common(pl, (uintptr_t)d_in | (uintptr_t)d_out, nframes, in_pitch, out_pitch, d);
+    if (st != CSIC_OK) return st;
+    d->args.in = static_cast<const uint32_t *>(d_in);
+    d->args.out = static_cast<uint32_t *>(d_out);
+    return CSIC_OK;
+}
+
+int prepare_launch_table(const csic_plan *pl, const void *const *d_in_tab, void *const *d_out_tab, uintptr_t align_bits, int nframes,
+                         LaunchDesc *d)
+{
+    if (!pl) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
+    if (!d_in_tab || !d_out_tab) return set_error(CSIC_EINVAL_NULL, "frame table is NULL");
+    const int st = prepare_common(pl, align_bits, nframes, 0, 0, d);
+    if (st != CSIC_OK) return st;
+    d->args.in_tab = reinterpret_cast<const uint32_t *const *>(d_in_tab);
+    d->args.out_tab = reinterpret_cast<uint32_t *const *>(d_out_tab);
     return CSIC_OK;
 }
 

@@ -230,7 +230,7 @@ int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *
  * hipGraph chain -- pays.  A frame graph records one launch per frame once (frame k: d_in[k] -> d_out[k]; same
  * preconditions as csic_process_device) and replays them so that independent frames overlap.  The reference
  * processes images strictly one after the other (ImageCompressorTopApp.scala:23-145, a fresh DUT per image);
- * frames are independent, so no ordering between them has to be kept.  Two backends:
+ * frames are independent, so no ordering between them has to be kept.  Three backends:
  *
  *   CSIC_FRAME_GRAPH_HIP     `branches` hipGraph chains (kernel nodes identical to the eager launch), chain 0
  *                            replayed on the caller's stream, the others on internal streams forked from and
@@ -266,6 +266,12 @@ int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *
  *                            stream-ordered launch costs 17-40 us of signal hand-offs (1-3 queues) on top of the
  *                            host-ordered time: record many frames per graph.
  *
+ *   CSIC_FRAME_GRAPH_FUSED   not per-frame launches at all: ONE kernel launch covers every frame (frame index on the
+ *                            grid's z axis, the frame bases read from a device-resident pointer table the graph owns), so
+ *                            frames in separate buffers run exactly like csic_process_batch_device's contiguous batch.
+ *                            csic_frame_graph_launch is an ordinary asynchronous launch on `hip_stream`: fully ordered,
+ *                            hipGraph-capturable, no internal streams or queues (`branches` is ignored).
+ *
  * A graph, like a plan, is not thread-safe (one thread at a time per graph; different graphs may be used from different
  * threads, the library serialises their access to its queues).
  * branches <= 0 selects the backend's default for the frame size (more overlap for smaller frames; measured table
@@ -274,6 +280,7 @@ int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *
  * CSIC_FRAME_GRAPH_HIP. */
 #define CSIC_FRAME_GRAPH_HIP    0
 #define CSIC_FRAME_GRAPH_DIRECT 1
+#define CSIC_FRAME_GRAPH_FUSED  2
 #define CSIC_FRAME_GRAPH_DEFAULT_BRANCHES 4   /* HIP backend, small frames (2 chains when a frame is >= 5 us of HBM time)          */
 #define CSIC_FRAME_GRAPH_DEFAULT_QUEUES   3   /* DIRECT backend, small frames (2 queues from 2.5 us, 1 queue from 10 us per frame); see below */
 typedef struct csic_frame_graph csic_frame_graph;

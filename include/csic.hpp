@@ -156,7 +156,7 @@ private:
 // so that small launches overlap.  HIP = hipGraph chains ordered with the caller's stream; DIRECT = AQL packets without
 // barrier bits on the library's own queues -- launch(stream) orders them with a HIP stream on the device, submit()/wait()
 // by the host.  The reference processes one image at a time (ImageCompressorTopApp.scala:53-68).
-enum class FrameGraphBackend : int32_t { HIP = CSIC_FRAME_GRAPH_HIP, DIRECT = CSIC_FRAME_GRAPH_DIRECT };
+enum class FrameGraphBackend : int32_t { HIP = CSIC_FRAME_GRAPH_HIP, DIRECT = CSIC_FRAME_GRAPH_DIRECT, FUSED = CSIC_FRAME_GRAPH_FUSED };
 
 class FrameGraph {
 public:

@@ -42,7 +42,7 @@ int main()
     for (int k = 0; k < n; ++k) CS(csic_checksum_device(ref[k], (int64_t)opx, &want[k], st));
 
     int fails = 0;
-    for (int backend : {CSIC_FRAME_GRAPH_HIP, CSIC_FRAME_GRAPH_DIRECT}) {
+    for (int backend : {CSIC_FRAME_GRAPH_HIP, CSIC_FRAME_GRAPH_DIRECT, CSIC_FRAME_GRAPH_FUSED}) {
         csic_frame_graph *g = nullptr;
         CS(csic_frame_graph_create_ex(plan, cin.data(), out.data(), n, 0, backend, &g));
         int32_t nf = 0, nb = 0;
@@ -75,7 +75,7 @@ int main()
                 if (got != want[k]) { std::printf("FAIL submit/wait frame %d\n", k); ++fails; }
             }
         }
-        std::printf("backend %s: %d frames, %d chain(s)/queue(s), launch %s: ok\n", backend == CSIC_FRAME_GRAPH_HIP ? "HIP" : "DIRECT", nf, nb,
+        std::printf("backend %s: %d frames, %d chain(s)/queue(s), launch %s: ok\n", backend == CSIC_FRAME_GRAPH_HIP ? "HIP" : backend == CSIC_FRAME_GRAPH_DIRECT ? "DIRECT" : "FUSED", nf, nb,
                     ordered == 1 ? "ordered with the stream on the device" : "host-ordered");
         CS(csic_frame_graph_destroy(g));
     }

@@ -52,4 +52,4 @@ def test_frame_graph_c_abi_from_native_hip_host_code():
                                "-L" + PKG, "-lcsic_hip", "-Wl,-rpath," + PKG, "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
-    assert "backend DIRECT" in r.stdout and "backend HIP" in r.stdout
+    assert "backend DIRECT" in r.stdout and "backend HIP" in r.stdout and "backend FUSED" in r.stdout

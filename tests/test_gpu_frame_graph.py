@@ -26,7 +26,7 @@ def _oparams(orc, W, H, a, b, bits, f, op=CSQ, rounding=0):
                             cr_bits=bits[2], factor=f, op=op, rounding=rounding)
 
 
-@pytest.mark.parametrize("backend", ["hip", "direct"])
+@pytest.mark.parametrize("backend", ["hip", "direct", "fused"])
 @pytest.mark.parametrize("branches", [1, 2, 3, None, 64])
 def test_frame_graph_small_frames(csic, oracle, branches, backend):
     """7 frames in SEPARATE allocations (not one contiguous batch), every chain layout."""
@@ -49,7 +49,7 @@ def test_frame_graph_small_frames(csic, oracle, branches, backend):
                     assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(want.shape), want), (rep, k)
 
 
-@pytest.mark.parametrize("backend", ["hip", "direct"])
+@pytest.mark.parametrize("backend", ["hip", "direct", "fused"])
 def test_frame_graph_every_kernel_family(csic, oracle, backend):
     """f = 1 vector kernel, k_dec in both order classes, k_generic and the AVG extension through graph nodes."""
     import torch
@@ -89,6 +89,41 @@ def test_frame_graph_errors(csic):
         assert N.lib().csic_frame_graph_create(pl._h, pin, pin, 0, 1, C.byref(h)) == N.EINVAL_SIZE
         assert N.lib().csic_frame_graph_launch(None, None) == N.EINVAL_NULL
         assert N.lib().csic_frame_graph_destroy(None) == 0
+
+
+def test_fused_graph_unaligned_frames_and_stream_capture(csic, oracle):
+    """FUSED backend: frames at pointers that are only 4-byte aligned make the whole launch take the 4-byte kernels; the
+    launch is an ordinary kernel launch, so it can be captured into a hipGraph of the caller's own."""
+    import torch
+    W, H, n = 256, 24, 5
+    cp = csic.make_c_params(W, H, 2, 2, 6, 5, 5, 1, CSQ)
+    host = [oracle.synth_frame(W * H, 300 + k) for k in range(n)]
+    want = [oracle.process(_oparams(oracle, W, H, 2, 2, (6, 5, 5), 1), h, form="closed") for h in host]
+    with csic.Plan(cp, 0) as pl:
+        assert pl.kernel_name.startswith("k_f1x4")
+        pool = torch.zeros(n * (W * H + 1) + 1, dtype=torch.int32, device="cuda:0")
+        d_ins = []
+        for k, h in enumerate(host):
+            off = k * (W * H + 1) + 1                                    # every second frame off the 16-byte grid
+            d_ins.append(pool[off:off + W * H])
+            d_ins[-1].copy_(torch.from_numpy(h.view(np.int32)))
+        d_outs = [torch.zeros(W * H, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+        with csic.FrameGraph(pl, d_ins, d_outs, backend="fused") as g:
+            assert g.branches == 1 and g.stream_ordered
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                g.launch(side)                                            # warm-up outside capture
+            torch.cuda.current_stream().wait_stream(side)
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                g.launch()
+            for t in d_outs:
+                t.zero_()
+            cg.replay()
+            torch.cuda.synchronize()
+        for k in range(n):
+            assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(H, W), want[k]), k
 
 
 def test_direct_graph_many_outstanding_submissions(csic, oracle):
@@ -209,7 +244,8 @@ def test_entry_points_leave_the_callers_device_current(csic):
 def test_cfg5_literal_64_frames_graph_and_batched(csic, oracle):
     """BASELINE.json configs[4] at full size: 64 x 3840x2160 ARGB (2.1 GB, generated on the device), 4:2:0, sf=4,
     bits 3/3/2.  (1) one hipGraph of 64 per-frame launches in a single chain, (2) three hipGraph chains on three
-    streams, (3) the direct AQL backend on four queues, (4) one batched launch; all 64 x 4 outputs against
+    streams, (3) the direct AQL backend on four queues, (4) the fused backend (one launch over a pointer table), (5) one
+    batched launch; all 64 x 5 outputs against
     orc_process_closed_mt on host copies of the frames."""
     import torch
     W, H, n = 3840, 2160, 64
@@ -223,10 +259,10 @@ def test_cfg5_literal_64_frames_graph_and_batched(csic, oracle):
         d_in = torch.empty(n * ipx, dtype=torch.int32, device="cuda:0")
         sh = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         N.check(lib.csic_synth_frame_device(C.c_void_p(d_in.data_ptr()), d_in.numel(), 0, 20250629, sh))
-        outs = {name: torch.zeros(n * opx, dtype=torch.int32, device="cuda:0") for name in ("chain", "forked", "direct", "batched")}
+        outs = {name: torch.zeros(n * opx, dtype=torch.int32, device="cuda:0") for name in ("chain", "forked", "direct", "fused", "batched")}
         frames_in = [d_in[k * ipx:(k + 1) * ipx] for k in range(n)]
         torch.cuda.synchronize()
-        for name, br, backend in (("chain", 1, "hip"), ("forked", 3, "hip"), ("direct", 4, "direct")):
+        for name, br, backend in (("chain", 1, "hip"), ("forked", 3, "hip"), ("direct", 4, "direct"), ("fused", 1, "fused")):
             with csic.FrameGraph(pl, frames_in, [outs[name][k * opx:(k + 1) * opx] for k in range(n)], branches=br,
                                  backend=backend) as g:
                 assert (g.nframes, g.branches) == (n, br)

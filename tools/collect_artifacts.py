@@ -29,13 +29,13 @@ def small_launch_md(src, dst, tag):
                  "Source: `tools/small_launch.py` through the C ABI (`csic_frame_graph_*`), one MI355X, 64-256 launches per graph over a ring of\n"
                  f"distinct frames; raw lines in `{tag}_small_launch.jsonl`.  `hip` = CSIC_FRAME_GRAPH_HIP (hipGraph chains on pooled streams,\n"
                  "HIP events per replay), `direct` = CSIC_FRAME_GRAPH_DIRECT (AQL packets without barrier bits on the library's own queues, host wall\n"
-                 "clock over 30 submissions in flight).  Each cell: µs per launch (% of the 8 TB/s roofline, algorithmic bytes). `bN` = N chains / queues.\n\n")
+                 "clock over 30 submissions in flight), `fused` = CSIC_FRAME_GRAPH_FUSED (one launch over all nodes through a pointer table, b1 only).  Each cell: µs per launch (% of the 8 TB/s roofline, algorithmic bytes). `bN` = N chains / queues.\n\n")
         for (case, shape), d in tab.items():
             fh.write(f"## {case} — {shape}, `{d['kernel']}`\n\n{d['alg']:,} algorithmic bytes per launch, floor {d['floor']} µs at 8 TB/s")
             if "batched" in d:
                 fh.write(f"; {d['batched'][2]}: **{d['batched'][0]} µs per frame ({100 * d['batched'][1]:.1f} %)**")
             fh.write("\n\n| backend | block threads | b1 | b2 | b3 | b4 | b6 | b8 |\n|---|---|---|---|---|---|---|---|\n")
-            for be in ("hip", "direct"):
+            for be in ("hip", "direct", "fused"):
                 for thr in (0, 256, 128, 64):
                     cells = [d.get((be, thr, b)) for b in (1, 2, 3, 4, 6, 8)]
                     if not any(cells):

@@ -71,7 +71,7 @@ while time.time() < t_end:
             wants = [want] + [orc.process(op_, fr, "avg" if avg else "closed") for fr in frames[1:]]
             d_ins = [torch.from_numpy(fr.view(np.int32)).cuda() for fr in frames]
             d_outs = [torch.zeros(pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0") for _ in range(nf)]
-            backend = "direct" if rng.random() < 0.6 else "hip"
+            backend = ["direct", "direct", "hip", "fused"][int(rng.integers(0, 4))]
             br = [None, 1, 2, 3, 4, 8][int(rng.integers(0, 6))]
             torch.cuda.synchronize()
             with csic.FrameGraph(pl, d_ins, d_outs, branches=br, backend=backend) as g:

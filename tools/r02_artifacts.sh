@@ -26,6 +26,7 @@ bench)
   $BN --config cfg5 --per-frame-graph --issue hip --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $BN --config cfg5 --per-frame-graph --issue direct --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $BN --config cfg5 --per-frame-graph --issue direct --direct-queues 4 --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  $BN --config cfg5 --per-frame-graph --issue fused --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config cfg2 --frames-per-step 4096 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config cfg3 --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config sq1000 --order scq --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1

@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--branches", default="1,2,3,4,6,8")
     ap.add_argument("--threads", default="0,128", help="CSIC_TUNE_BLOCK_THREADS values; 0 = the library's default choice")
-    ap.add_argument("--backends", default="hip,direct")
+    ap.add_argument("--backends", default="hip,direct,fused")
     args = ap.parse_args()
 
     import torch
@@ -116,7 +116,7 @@ def main():
           plan.tune(N.TUNE_BLOCK_THREADS, thr)
           for backend in args.backends.split(","):
             for br in branches_list:
-                if br > nodes or (backend == "direct" and br > 8) or (backend == "hip" and br > 16):
+                if br > nodes or (backend == "direct" and br > 8) or (backend == "hip" and br > 16) or (backend == "fused" and br != 1):
                     continue
                 g = csic.FrameGraph(plan, d_ins, d_outs, branches=br, backend=backend)
                 prewarm(g)
