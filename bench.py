@@ -143,7 +143,9 @@ class Workload:
         "serial": one eager launch per step on the launch stream (N = 1 headline: the roofline contract);
         "hip"   : the same launches from a frame graph, CSIC_FRAME_GRAPH_HIP (hipGraph chains ordered with the stream);
         "direct": the same launches from a frame graph, CSIC_FRAME_GRAPH_DIRECT (AQL packets without barrier bits on the
-                  library's queues, gated by and awaited on the launch stream through HIP signal memory)."""
+                  library's queues, gated by and awaited on the launch stream through HIP signal memory);
+        "fused" : the recorded frames as ONE launch over a pointer table, CSIC_FRAME_GRAPH_FUSED (a comparison point for
+                  --per-frame-graph: no longer one launch per frame)."""
         N = csic._native
         lib = N.lib()
         self.N, self.lib, self.torch, self.dev, self.args = N, lib, torch, dev, args
@@ -161,7 +163,7 @@ class Workload:
         N.check(lib.csic_stripe_rows(C.byref(gparams), parts, part, C.byref(r0), C.byref(nr), C.byref(o0), C.byref(on)))
         self.row0, self.stripe_rows = r0.value, nr.value
         if self.stripe_rows == 0:
-            raise SystemExit(f"rank {rank}: empty stripe ({gH} rows over {world} ranks)")
+            raise SystemExit(f"rank {part}: empty stripe ({gH} rows over {parts} ranks)")
         self.plan = csic.Plan(csic.make_c_params(W, self.stripe_rows, a, b, *bits, f, order, sampling=sampling), dev_index)
         if args.variant >= 0:
             self.plan.tune(N.TUNE_VARIANT, args.variant)
