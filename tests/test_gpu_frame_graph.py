@@ -334,3 +334,28 @@ def test_distinct_graphs_from_distinct_threads_share_the_engine(csic, oracle):
         t.join(timeout=120)
     assert not errors, errors
     assert results == {0: True, 1: True, 2: True}
+
+
+@pytest.mark.parametrize("backend", ["fused", "direct"])
+def test_frame_graph_at_the_frame_count_limit(csic, oracle, backend):
+    """65 536 frames (the API's maximum) in one graph: the fused backend needs two launches (grid z stops at 65 535), the
+    direct backend pushes ~21 800 packets through each 4096-packet ring in chunks."""
+    import torch
+    W, H, n = 8, 4, 65536
+    cp = csic.make_c_params(W, H, 2, 0, 8, 8, 8, 2, CSQ)
+    host = oracle.synth_frame(n * W * H, 123)
+    with csic.Plan(cp, 0) as pl:
+        opx = pl.out_width * pl.out_height
+        d_in = torch.from_numpy(host.view(np.int32)).cuda()
+        d_out = torch.zeros(n * opx, dtype=torch.int32, device="cuda:0")
+        ref = torch.zeros_like(d_out)
+        pl.process_device(d_in, ref, nframes=n)
+        torch.cuda.synchronize()
+        with csic.FrameGraph(pl, [d_in[k * W * H:(k + 1) * W * H] for k in range(n)],
+                             [d_out[k * opx:(k + 1) * opx] for k in range(n)], backend=backend) as g:
+            g.launch()
+            torch.cuda.synchronize()
+        assert torch.equal(ref, d_out)
+        for k in (0, 1, 65534, 65535):
+            want = oracle.process(_oparams(oracle, W, H, 2, 0, (8, 8, 8), 2), host[k * W * H:(k + 1) * W * H], form="closed")
+            assert np.array_equal(d_out[k * opx:(k + 1) * opx].cpu().numpy().view(np.uint32), want.reshape(-1)), k
