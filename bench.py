@@ -4,9 +4,14 @@
 Metric (BASELINE.json): input Mpixels/s end to end (RGB -> YCbCr -> 4:2:0 -> reconstruct), device
 resident packed ARGB in HBM -> reconstructed packed ARGB in HBM, plus the fraction of the HBM roofline.
 
-Workload: BASELINE.json configs[3] ("cfg 4" of SURVEY.md 8): ONE synthetic 8192x8192 RGB frame per step,
-4:2:0, sf=2, no quantisation, order chroma->spatial->quant.
-  N = 1 : one step = one frame = one kernel launch.
+Workload: BASELINE.json configs[3] ("cfg 4" of SURVEY.md 8): synthetic 8192x8192 RGB frames, 4:2:0, sf=2, no
+quantisation, order chroma->spatial->quant.  One STEP = one pass of the hot path over one batch of 64 distinct
+frames resident in HBM (16 GiB of input), every frame its own kernel launch (`config.launches_per_step`; the
+roofline figures are per launch).  The batch exists for the clock, not for the kernel: the driver times K = 20
+steps between barriers, and 20 single-frame steps are 0.65 ms of GPU work at N = 1 and 0.08 ms at N = 8 -- less
+than the barrier + synchronize that brackets them (measured: one rank's 8192x1024 stripe costs 9.3 us per launch
+when 20 of them are timed, 4.1 us when thousands are; profiles/r02_k20_steps.jsonl).
+  N = 1 : 64 eager launches per step on one HIP stream, one frame each.
   N > 1 : (one process per GPU, launched by torch.distributed.run) the SAME 8192x8192 frame is row-striped
           over the N ranks -- STRONG scaling, what configs[3] and the north star name ("Images shard by
           row-stripe across the 8 GPUs"): rank r owns the aligned stripe csic_stripe_rows gives it
@@ -15,7 +20,7 @@ Workload: BASELINE.json configs[3] ("cfg 4" of SURVEY.md 8): ONE synthetic 8192x
           strong split.  The weak-scaling number (global frame 8192 x 8192*N, one full 8192x8192 stripe per
           rank) is measured afterwards in the same process and reported beside it as "weak": {...}.
 
-Frames rotate through a ring of distinct device buffers (8 GiB of input per GPU by default) far larger
+Frames rotate through a ring of distinct device buffers (16 GiB of input per GPU by default) far larger
 than the 256 MiB Infinity Cache, so the kernel streams from HBM, not from L3.
 
 Prints ONE JSON line on rank 0.
@@ -52,6 +57,10 @@ AVG_CONFIGS = {"avg_8k_420_sf2": "cfg4", "avg_4k_420_sf4": "cfg5"}
 for _k, _v in AVG_CONFIGS.items():
     CONFIGS[_k] = CONFIGS[_v]
 CSQ = (3, 1, 2)
+# launches per step (--batch-frames 0): the headline config times batches of frames, each frame its own launch, so that the
+# K = 20 steps the driver asks for are milliseconds of GPU work at every N; the others stay at one launch per step
+DEFAULT_BATCH = {"cfg4": 64}
+GRAPH_CAP = 4096           # launches per frame-graph replay (a gated direct submission must fit the 4096-packet rings)
 SCQ = (1, 3, 2)            # spatial before chroma (the reference app's default order class)
 
 
@@ -253,35 +262,41 @@ class Workload:
             def step(i):
                 return lib.csic_process_batch_device(ph, in_ptrs[i % nring], out_ptrs[i % nring], fps, sh)
         self.step = step
-        # issue = "hip" / "direct": the one-launch steps come from a pre-built frame graph over the ring -- the SAME
-        # launches, one per step, replayed nring steps at a time on the launch stream (ragged ends stay eager).  A
-        # strong-scaling stripe at N = 8 is a 3 us launch: a Python loop cannot enqueue those fast enough, and
-        # independent steps that overlap hide each other's launch boundary (profiles/r02_small_launch.md).
+        # issue = "hip" / "direct": the one-frame launches come from a pre-built frame graph -- the SAME launches, one per
+        # frame, launch j on ring slot j % nring, up to GRAPH_CAP of them per replay on the launch stream.  A strong-scaling
+        # stripe at N = 8 is a 3 us launch: a Python loop cannot enqueue those fast enough, and independent launches that
+        # overlap hide each other's launch boundary (profiles/r02_small_launch.md).
+        self.graph_len = 0
         if self.issue != "serial" and not self.per_frame_graph and fps == 1 and args.streams <= 1:
-            self.step_graph = csic.FrameGraph(self.plan, self.ins, self.outs, backend=backend,
-                                              branches=(args.direct_queues if backend == "direct" else args.step_chains) or None)
-            self.launch_desc = describe(self.step_graph, f"one launch per step; {nring} consecutive steps (the ring)")
-            # the ragged end of the K timed steps (K % nring) comes from a second, shorter graph instead of a Python loop
-            rem = args.steps % nring
+            total = max(1, args.steps * args.batch)                      # launches in the timed region
+            self.graph_len = glen = min(total, GRAPH_CAP)
+            br = (args.direct_queues if backend == "direct" else args.step_chains) or None
+            self.step_graph = csic.FrameGraph(self.plan, [self.ins[j % nring] for j in range(glen)],
+                                              [self.outs[j % nring] for j in range(glen)], backend=backend, branches=br)
+            self.launch_desc = describe(self.step_graph, f"one launch per frame; {glen} consecutive launches (ring of {nring} frames)")
+            # the ragged end of the timed launches comes from a second, shorter graph instead of a Python loop
+            rem = total % glen
             if rem:
-                self.rem_graph = csic.FrameGraph(self.plan, self.ins[:rem], self.outs[:rem], backend=backend,
+                self.rem_graph = csic.FrameGraph(self.plan, [self.ins[j % nring] for j in range(rem)],
+                                                 [self.outs[j % nring] for j in range(rem)], backend=backend,
                                                  branches=self.step_graph.branches)
 
     def run_steps(self, first, count):
-        """Issues steps first .. first+count-1 (asynchronous).  Returns the OR of the launch statuses."""
+        """Issues launches first .. first+count-1 (asynchronous; a step is args.batch of them).  Returns the OR of the
+        launch statuses."""
         st = 0
         if self.step_graph is None:
             step = self.step
             for i in range(first, first + count):
                 st |= step(i)
             return st
-        nring, i, end = self.nring, first, first + count
+        glen, i, end = self.graph_len, first, first + count
         rem = self.rem_graph.nframes if self.rem_graph is not None else 0
-        while i < end:                                      # whole-ring graph replays; ragged ends: the short graph, else eager
-            if i % nring == 0 and end - i >= nring:
+        while i < end:                                      # whole graph replays; ragged ends: the short graph, else eager
+            if end - i >= glen:
                 self.step_graph.launch(self.stream)
-                i += nring
-            elif rem and i % nring == 0 and end - i == rem:
+                i += glen
+            elif rem and end - i == rem:
                 self.rem_graph.launch(self.stream)
                 i += rem
             else:
@@ -302,7 +317,8 @@ class Workload:
 
 
 def timed_run(wl, args, torch, dist, world, backend, dev):
-    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides.
+    """W untimed warm-up steps, then EXACTLY K steps (of args.batch launches each) bracketed by barrier + synchronize on
+    both sides.
     Returns (elapsed seconds: max over ranks, kernel ms per launch from HIP events on the launch stream)."""
     N, stream = wl.N, wl.stream
 
@@ -314,11 +330,12 @@ def timed_run(wl, args, torch, dist, world, backend, dev):
     if args.prewarm_ms > 0:                                       # clock conditioning, untimed
         t_end = time.perf_counter() + args.prewarm_ms * 1e-3
         i = 0
+        chunk = wl.graph_len or 64
         while time.perf_counter() < t_end:
-            wl.run_steps(i, 64)
-            i += 64
+            wl.run_steps(i, chunk)
+            i += chunk
             torch.cuda.synchronize(dev)
-    if wl.run_steps(0, args.warmup) != 0:
+    if wl.run_steps(0, args.warmup * args.batch) != 0:
         N.check(wl.step(0))
     barrier()
 
@@ -326,7 +343,7 @@ def timed_run(wl, args, torch, dist, world, backend, dev):
     # ev0/ev1 are HIP events recorded on the launch stream around the K steps: (ev1 - ev0) / launches is the
     # average launch duration the roofline uses (it includes the ~1-2 us inter-kernel boundary, so it is an
     # upper bound on the per-kernel time rocprofv3 reports).
-    K = args.steps
+    K = args.steps * args.batch                                   # launches (per-frame-graph configs: graph replays)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
@@ -361,7 +378,7 @@ def host_ordered_direct(wl, K, torch, dist, world, backend, dev):
     """issue=direct only: the same graphs through csic_frame_graph_submit / _wait (ordered by the host, no gate and no
     stream waits), wall clock between barriers; whole graph replays only, so the step count is rounded down."""
     graphs = wl.graphs if wl.per_frame_graph else [wl.step_graph]
-    per = 1 if wl.per_frame_graph else wl.nring
+    per = 1 if wl.per_frame_graph else wl.graph_len
     reps = max(1, K // per)
 
     def run():
@@ -392,8 +409,11 @@ def host_ordered_direct(wl, K, torch, dist, world, backend, dev):
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3000)
-    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = 3200 launches' worth: 50 for cfg4, 3200 at one launch per step)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed warm-up steps (-1 = 512 launches' worth)")
+    ap.add_argument("--batch-frames", type=int, default=0,
+                    help="launches per step: a step is one pass over this many distinct resident frames, each frame its own launch "
+                         "(0 = config default: 64 for cfg4, else 1).  ms_per_step covers the whole batch; every roofline figure is per launch")
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed conditioning before the W warm-up steps: replay the same launches for this long so "
                          "the GPU reaches its steady-state clocks (a 33 us step does not ramp DPM in 40 launches: "
@@ -411,7 +431,7 @@ def main(argv=None):
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak", "both"],
                     help="N>1: strong (default; `value` = ONE frame of the config split N ways, the weak number is measured "
                          "afterwards and reported beside it), weak (`value` = one full frame per rank), both == strong")
-    ap.add_argument("--ring-mib", type=int, default=8192,
+    ap.add_argument("--ring-mib", type=int, default=16384,
                     help="input bytes rotated through (MiB), per GPU.  Measured on cfg4: 2 frames (partly Infinity-"
                          "Cache resident) 31.8 us, 8 frames 32.5 us, 32 and 64 frames 32.65 us -- the default is the "
                          "converged, HBM-only regime")
@@ -430,7 +450,7 @@ def main(argv=None):
                          "AQL packets without barrier bits), both ordered with the launch stream and timed by the same HIP events; fused = "
                          "the recorded frames as ONE launch over a pointer table (not per-frame launches; for --per-frame-graph comparisons).  "
                          "auto: N=1 serial (the roofline contract: the profiler's per-kernel average must describe the timed launches); "
-                         "N>1 pre-recorded launches -- hip while a step is >= 5 us of HBM time (N <= 4 for cfg4), direct below (N = 8; "
+                         "N>1 pre-recorded launches -- hip while a launch is >= 7 us of HBM time (N = 2 for cfg4), direct below (N = 4, 8; "
                          "falls back to hip if the runtime refuses)")
     ap.add_argument("--step-chains", type=int, default=0,
                     help="issue hip: hipGraph chains among consecutive steps (0 = library default for the stripe size, 1 = single-stream order)")
@@ -455,9 +475,19 @@ def main(argv=None):
                     help="N=1 only: process rank 0's stripe of an N-way strong split (8192 x 8192/N) exactly as a rank of "
                          "`--gpus N` would (same stripe, same issue mode, same ring), to measure on one GPU what each rank of the "
                          "N-GPU run does; `value` is then that ONE rank's rate")
+    ap.add_argument("--idle-streams", type=int, default=0,
+                    help="EXPERIMENT: create this many extra HIP streams, run one tiny op on each and leave them idle -- what a rank of "
+                         "an RCCL job has beside its launch stream (the communicator's streams own hardware queues too); checks that idle "
+                         "queues do not push the frame-graph backends' queues into time-slicing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = ap.parse_args(argv)
+    args.batch = args.batch_frames if args.batch_frames > 0 else \
+        (DEFAULT_BATCH.get(args.config, 1) if args.frames_per_step <= 0 and not args.per_frame_graph else 1)
+    if args.steps <= 0:
+        args.steps = max(1, 3200 // args.batch)
+    if args.warmup < 0:
+        args.warmup = max(1, 512 // args.batch)
 
     import torch
     import torch.distributed as dist
@@ -493,20 +523,28 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
+    idle = []
+    for _ in range(args.idle_streams):
+        sd = torch.cuda.Stream(dev)
+        with torch.cuda.stream(sd):
+            idle.append((sd, torch.zeros(1024, device=dev) + 1))
+    torch.cuda.synchronize(dev)
+
     W, H, a, b, bits, f, _ = CONFIGS[args.config]
     K = args.steps
+    KL = K * args.batch                                             # launches (or graph replays) in the timed region
     headline_mode = "weak" if args.scaling == "weak" else "strong"
 
     # ---- headline run --------------------------------------------------------------------------------
     if args.issue != "auto":
         issue = args.issue
     else:
-        # N > 1: pre-recorded launches.  Measured per stripe size (profiles/r02_bench_stripe_of.jsonl): from 8192x2048 up
-        # the HIP backend's two chains are as fast as direct dispatch behind its stream hand-offs (8.12 vs 8.20 us, 15.80 vs
-        # 16.36 us); at 8192x1024 direct dispatch wins (4.06 vs 4.40 us).  The split point is 5 us of HBM time per step.
+        # N > 1: pre-recorded launches.  Measured per stripe size (profiles/r02_bench_stripe_of.jsonl): at 8192x4096 the HIP
+        # backend's two chains beat direct dispatch (15.40 vs 16.38 us per launch); from 8192x2048 down direct dispatch wins
+        # (7.99 vs 8.22 us, 4.00 vs 4.29 us).  The split point is 7 us of HBM time per launch.
         parts = args.stripe_of if (world == 1 and args.stripe_of > 1) else world
         step_floor_us = 4.0 * W * (-(-H // f) + -(-W // f) * -(-H // f) / W) / parts / (HBM_PEAK_GBS * 1e3)
-        issue = "serial" if parts == 1 else ("direct" if step_floor_us < 5.0 else "hip")
+        issue = "serial" if parts == 1 else ("direct" if step_floor_us < 7.0 else "hip")
     issue_note = None
     try:
         wl = Workload(args, csic, torch, dev, dev_index, world, rank, headline_mode, issue)
@@ -523,13 +561,13 @@ def main(argv=None):
             issue, issue_note = "hip", "direct dispatch unavailable on some rank; all ranks use issue=hip"
             wl = Workload(args, csic, torch, dev, dev_index, world, rank, headline_mode, issue)
     elapsed, kern_ms_avg = timed_run(wl, args, torch, dist, world, args.backend, dev)
-    total_px = allsum(float(wl.in_px) * wl.fps * K)                # real per-rank pixel counts, summed
+    total_px = allsum(float(wl.in_px) * wl.fps * KL)               # real per-rank pixel counts, summed
     value = total_px / elapsed / 1e6
     achieved = wl.alg_bytes / (kern_ms_avg * 1e-3) / 1e9
     stream = wl.stream
 
     # ---- diagnostic (untimed): an event pair around each of a few launches --------------------------
-    npair = min(K, 50)
+    npair = min(KL, 50)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(npair)]
     for i in range(npair):
         ev[i][0].record(stream)
@@ -557,12 +595,13 @@ def main(argv=None):
 
     head = {"stripe_rows": wl.stripe_rows, "global_rows": wl.global_rows, "nring": wl.nring, "kernel": wl.plan.kernel_name,
             "launch": wl.launch_desc, "alg_bytes": wl.alg_bytes, "lpf": wl.lpf, "out_px": wl.out_px, "in_px": wl.in_px,
-            "fps": wl.fps}
+            "fps": wl.fps, "launches_per_replay": wl.launches_per_step}
     head_host_ordered = None
     if issue == "direct" and (wl.step_graph is not None or wl.per_frame_graph):
-        elh, nsteps = host_ordered_direct(wl, K, torch, dist, world, args.backend, dev)
+        elh, nsteps = host_ordered_direct(wl, KL, torch, dist, world, args.backend, dev)
         pxh = allsum(float(wl.in_px) * wl.fps * nsteps)
-        head_host_ordered = {"value": round(pxh / elh / 1e6, 1), "ms_per_step": round(elh * 1e3 / nsteps, 5), "steps": nsteps,
+        head_host_ordered = {"value": round(pxh / elh / 1e6, 1), "ms_per_step": round(elh * 1e3 / nsteps * args.batch, 5),
+                             "steps": nsteps / args.batch, "ms_per_launch": round(elh * 1e3 / nsteps, 5),
                              "roofline_frac_rank0": round(wl.alg_bytes * wl.launches_per_step * nsteps / elh / 1e9 / HBM_PEAK_GBS, 4),
                              "how": "the headline's graphs through csic_frame_graph_submit/_wait: no gate, no stream waits, host wall clock"}
     wl.close()
@@ -571,15 +610,16 @@ def main(argv=None):
         """The same K steps in another scaling mode / issue mode, same process, same timing method."""
         w2 = Workload(args, csic, torch, dev, dev_index, world, rank, scaling, how)
         el2, km2 = timed_run(w2, args, torch, dist, world, args.backend, dev)
-        px2 = allsum(float(w2.in_px) * w2.fps * K)
+        px2 = allsum(float(w2.in_px) * w2.fps * KL)
         res = {"scaling": scaling, "value": round(px2 / el2 / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(el2 * 1e3 / K, 5),
-               "steps": K, "stripe_rows_per_gpu": w2.stripe_rows, "global_rows": w2.global_rows, "launch": w2.launch_desc,
+               "ms_per_launch": round(el2 * 1e3 / KL, 5), "steps": K, "stripe_rows_per_gpu": w2.stripe_rows, "global_rows": w2.global_rows, "launch": w2.launch_desc,
                "roofline_frac_rank0": round(w2.alg_bytes / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "kernel_ms_avg_rank0": round(km2, 5)}
         if how == "direct" and (w2.step_graph is not None or w2.per_frame_graph):
-            elh, nsteps = host_ordered_direct(w2, K, torch, dist, world, args.backend, dev)
+            elh, nsteps = host_ordered_direct(w2, KL, torch, dist, world, args.backend, dev)
             pxh = allsum(float(w2.in_px) * w2.fps * nsteps)
-            res["host_ordered"] = {"value": round(pxh / elh / 1e6, 1), "ms_per_step": round(elh * 1e3 / nsteps, 5), "steps": nsteps,
+            res["host_ordered"] = {"value": round(pxh / elh / 1e6, 1), "ms_per_step": round(elh * 1e3 / nsteps * args.batch, 5),
+                                   "steps": nsteps / args.batch, "ms_per_launch": round(elh * 1e3 / nsteps, 5),
                                    "roofline_frac_rank0": round(w2.alg_bytes * w2.launches_per_step * nsteps / elh / 1e9 / HBM_PEAK_GBS, 4),
                                    "how": "csic_frame_graph_submit/_wait: no gate, no stream waits, host wall clock"}
         w2.close()
@@ -621,11 +661,14 @@ def main(argv=None):
             "value": round(value, 1), "unit": "Mpixels/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / K, 5),
+            "ms_per_launch": round(elapsed * 1e3 / KL / head["launches_per_replay"], 5),
             "higher_is_better": True, "scaling": headline_mode, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: {W}x{H} ARGB, 4:{a}:{b}, bits {bits[0]}/{bits[1]}/{bits[2]}, sf={f}, "
-                            f"order {order_txt}, {head['fps']} frame(s)/step, FLOOR_HW",
+                            f"order {order_txt}, {head['fps'] * args.batch} frame(s)/step, FLOOR_HW",
+                "launches_per_step": args.batch * head["launches_per_replay"],
+                "frames_per_launch": head["lpf"],
                 "stripe_rows_per_gpu": head["stripe_rows"], "global_rows": head["global_rows"], "ring_frames": head["nring"],
                 "prewarm_ms": args.prewarm_ms,
                 "parallelism": (f"row-stripe x{world}, no data-path collective" if args.stripe_of <= 1 else
@@ -637,6 +680,7 @@ def main(argv=None):
                 "launch": head["launch"],
                 "issue": issue,
                 "streams": args.streams,
+                "idle_streams": args.idle_streams,
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

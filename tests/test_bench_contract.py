@@ -82,3 +82,11 @@ def test_committed_traffic_entries_carry_a_source_hash():
 def test_strong_scaling_is_the_default_for_n_gt_1():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'ap.add_argument("--scaling", default="strong"' in src
+
+
+def test_headline_step_is_a_batch_of_per_frame_launches():
+    """The driver times K = 20 steps: the headline config's step is a batch of frames, one launch each, so that the timed
+    region is milliseconds at every N; every other config stays at one launch per step."""
+    bench = _load_bench()
+    assert bench.DEFAULT_BATCH == {"cfg4": 64}
+    assert bench.GRAPH_CAP <= 4096

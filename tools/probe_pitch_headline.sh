@@ -4,6 +4,6 @@
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 for pad in 0 64 256 512 1024; do
   for thr in 0 128; do
-    python bench.py --no-cpu-baseline --pitch-pad $pad --block-threads $thr --steps 2000 --warmup 300 2>/dev/null || exit 1
+    python bench.py --no-cpu-baseline --pitch-pad $pad --block-threads $thr --batch-frames 1 --steps 2000 --warmup 300 2>/dev/null || exit 1
   done
 done

@@ -14,7 +14,7 @@ export TMPDIR=/tmp
 python3 "$ROOT/tools/srchash.py" > "$OUT/source_sha256.txt"
 cd /tmp
 # the kernel trace runs bench.py exactly as the driver does (defaults); the PMC passes skip the CPU baseline
-BENCH="python3 $ROOT/bench.py --config $CONFIG --no-cpu-baseline --steps 600 --warmup 100"
+BENCH="python3 $ROOT/bench.py --config $CONFIG --no-cpu-baseline --batch-frames 1 --steps 600 --warmup 100"
 if [ "$CONFIG" = "cfg4" ]; then TRACE="python3 $ROOT/bench.py"; else TRACE="$BENCH"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $TRACE > "$OUT/trace_bench.json" 2> "$OUT/trace.err" &&
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- $BENCH > "$OUT/fetch_bench.json" 2> "$OUT/fetch.err" &&

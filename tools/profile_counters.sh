@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_${TAG}_counters
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $ROOT/bench.py --steps 300 --warmup 50 --prewarm-ms 50 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --batch-frames 1 --steps 300 --warmup 50 --prewarm-ms 50 --no-cpu-baseline"
 rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --output-format csv -d "$OUT/sq1" -o sq1 -- $BENCH > "$OUT/sq1.json" 2> "$OUT/sq1.err"
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM --output-format csv -d "$OUT/sq2" -o sq2 -- $BENCH > "$OUT/sq2.json" 2> "$OUT/sq2.err"

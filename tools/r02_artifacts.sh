@@ -69,14 +69,16 @@ sweep)
 stripes)
   # what ONE rank of the N-GPU strong-scaling run does, measured alone on this GPU (bench.py --stripe-of N)
   J=$OUT/bench_stripe_of.jsonl; : > "$J"
-  for n in 2 4 8; do python bench.py --stripe-of $n --no-cpu-baseline >> "$J" 2>> "$OUT/bench.err" || exit 1; done
+  # with the driver's own flags (K = 20 steps, W = 5), N = 1 first, then one rank's share of N = 2, 4, 8
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline >> "$J" 2>> "$OUT/bench.err" || exit 1
+  for n in 2 4 8; do python bench.py --stripe-of $n --steps 20 --warmup 5 --no-cpu-baseline >> "$J" 2>> "$OUT/bench.err" || exit 1; done
   python - "$J" <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
     r = json.loads(l)
-    print(r["config"]["stripe_rows_per_gpu"], r["config"]["issue"], r["ms_per_step"], r["roofline"]["frac"],
-          {k: r[k]["ms_per_step"] for k in ("hip_streams", "direct_dispatch", "serial_launches", "direct_host_ordered") if k in r},
-          (r.get("direct_dispatch") or {}).get("host_ordered", {}).get("ms_per_step"))
+    print(r["config"]["stripe_rows_per_gpu"], r["config"]["issue"], r["ms_per_step"], r["ms_per_launch"], r["roofline"]["frac"],
+          {k: r[k]["ms_per_launch"] for k in ("hip_streams", "direct_dispatch", "serial_launches", "direct_host_ordered") if k in r},
+          (r.get("direct_dispatch") or {}).get("host_ordered", {}).get("ms_per_launch"))
 PY
   ;;
 *) echo "unknown stage $STAGE"; exit 2 ;;

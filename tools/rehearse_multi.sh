@@ -16,7 +16,7 @@ rc=$?
 tail -n 4 "$OUT/${TAG}_multi_rehearsal.halo.log"
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 \
-    bench.py --gpus 2 --backend gloo --steps 1000 --warmup 200 > "$OUT/${TAG}_multi_rehearsal.bench.log" 2>&1
+    bench.py --gpus 2 --backend gloo --steps 20 --warmup 5 > "$OUT/${TAG}_multi_rehearsal.bench.log" 2>&1
 rc=$?
 tail -n 2 "$OUT/${TAG}_multi_rehearsal.bench.log"
 exit $rc
