@@ -53,15 +53,26 @@ __device__ __forceinline__ void pin_args(const KArgs &a)
                  "s"(a.bdy), "s"(a.row_step), "s"(a.ip), "s"(a.op), "s"(a.in_tab), "s"(a.out_tab));
 }
 
+// Pixel pointers carry their address space.  A pointer that was itself loaded from memory (frame-table mode) is
+// a generic pointer to the compiler, and every access through it becomes a flat_load / flat_store with a 64-bit
+// per-lane address and an lgkmcnt dependency; the frames are always global memory, so say so.
+#define CSIC_GLOBAL __attribute__((address_space(1)))
+#define CSIC_CONSTANT __attribute__((address_space(4)))
+typedef const uint32_t CSIC_GLOBAL *gin_t;
+typedef uint32_t CSIC_GLOBAL *gout_t;
+
 // Base of the frame this block works on (grid z = frame): consecutive frames behind a.in / a.out, or -- frame-table mode --
-// whatever the device-resident tables name (one wave-uniform scalar load).
-__device__ __forceinline__ const uint32_t *frame_in(const KArgs &a)
+// whatever the device-resident tables name.  The tables are read through the constant address space (they are never
+// written while a kernel runs): one wave-uniform s_load, the frame base stays in SGPRs.
+__device__ __forceinline__ gin_t frame_in(const KArgs &a)
 {
-    return a.in_tab ? a.in_tab[blockIdx.z] : a.in + (int64_t)blockIdx.z * a.in_frame_px;
+    if (a.in_tab) return (gin_t)((const uint64_t CSIC_CONSTANT *)(uintptr_t)a.in_tab)[blockIdx.z];
+    return (gin_t)(uintptr_t)a.in + (int64_t)blockIdx.z * a.in_frame_px;
 }
-__device__ __forceinline__ uint32_t *frame_out(const KArgs &a)
+__device__ __forceinline__ gout_t frame_out(const KArgs &a)
 {
-    return a.out_tab ? a.out_tab[blockIdx.z] : a.out + (int64_t)blockIdx.z * a.out_frame_px;
+    if (a.out_tab) return (gout_t)((const uint64_t CSIC_CONSTANT *)(uintptr_t)a.out_tab)[blockIdx.z];
+    return (gout_t)(uintptr_t)a.out + (int64_t)blockIdx.z * a.out_frame_px;
 }
 
 enum { R_FLOOR = CSIC_ROUND_FLOOR_HW, R_TRUNC = CSIC_ROUND_TRUNC_SW };
@@ -77,16 +88,22 @@ enum { F_ARGB = CSIC_FMT_ARGB8888, F_YCC = CSIC_FMT_YCBCR888X };
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-template <bool NT> __device__ __forceinline__ uint32_t ld1(const uint32_t *p)
+template <bool NT> __device__ __forceinline__ uint32_t ld1(gin_t p)
 { return NT ? __builtin_nontemporal_load(p) : *p; }
-template <bool NT> __device__ __forceinline__ u32x4 ld4(const uint32_t *p)
-{ return NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p)) : *reinterpret_cast<const u32x4 *>(p); }
-template <bool NT> __device__ __forceinline__ void st1(uint32_t *p, uint32_t v)
+template <bool NT> __device__ __forceinline__ u32x4 ld4(gin_t p)
+{ typedef const u32x4 CSIC_GLOBAL *vp; return NT ? __builtin_nontemporal_load((vp)p) : *(vp)p; }
+template <bool NT> __device__ __forceinline__ void st1(gout_t p, uint32_t v)
 { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
-template <bool NT> __device__ __forceinline__ void st2(uint32_t *p, u32x2 v)
-{ if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(p)); else *reinterpret_cast<u32x2 *>(p) = v; }
-template <bool NT> __device__ __forceinline__ void st4(uint32_t *p, u32x4 v)
-{ if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p)); else *reinterpret_cast<u32x4 *>(p) = v; }
+template <bool NT> __device__ __forceinline__ void st2(gout_t p, u32x2 v)
+{ typedef u32x2 CSIC_GLOBAL *vp; if (NT) __builtin_nontemporal_store(v, (vp)p); else *(vp)p = v; }
+template <bool NT> __device__ __forceinline__ void st4(gout_t p, u32x4 v)
+{ typedef u32x4 CSIC_GLOBAL *vp; if (NT) __builtin_nontemporal_store(v, (vp)p); else *(vp)p = v; }
+// the same through plain pointers (kernel arguments: the compiler infers global itself; tools/ubench*.hip)
+template <bool NT> __device__ __forceinline__ uint32_t ld1(const uint32_t *p) { return ld1<NT>((gin_t)(uintptr_t)p); }
+template <bool NT> __device__ __forceinline__ u32x4 ld4(const uint32_t *p) { return ld4<NT>((gin_t)(uintptr_t)p); }
+template <bool NT> __device__ __forceinline__ void st1(uint32_t *p, uint32_t v) { st1<NT>((gout_t)(uintptr_t)p, v); }
+template <bool NT> __device__ __forceinline__ void st2(uint32_t *p, u32x2 v) { st2<NT>((gout_t)(uintptr_t)p, v); }
+template <bool NT> __device__ __forceinline__ void st4(uint32_t *p, u32x4 v) { st4<NT>((gout_t)(uintptr_t)p, v); }
 
 // ------------------------------------------------------------------------------------------------
 // per-pixel arithmetic
@@ -201,8 +218,8 @@ __global__ void __launch_bounds__(256) k_f1x4(KArgs a)
     const int W4 = a.W >> 2;
     const int x4 = blockIdx.x * a.bdx + threadIdx.x;
     if (x4 >= W4) return;
-    const uint32_t *in = frame_in(a);
-    uint32_t *out = frame_out(a);
+    const gin_t in = frame_in(a);
+    const gout_t out = frame_out(a);
     const int row_step = a.row_step;
     for (int row = blockIdx.y * a.bdy + threadIdx.y; row < a.H; row += row_step) {
         const int64_t base = (int64_t)row * a.ip + 4 * x4;
@@ -261,7 +278,7 @@ __device__ __forceinline__ uint32_t hold_in_quad(uint32_t v)
 // s_waitcnt vmcnt(0) in front of every store, which serialises the stores (38.0 vs 32.7 us per frame).
 // BCAST: the whole row replays one chroma pixel (`bpx`).
 template <int ROUND, int FMT, int F, int HOLD, bool BCAST, int K, bool NT, bool CHECK>
-__device__ __forceinline__ void dec_chunk(const KArgs &a, const uint32_t *rowp, uint32_t *orow, int co0, int bx,
+__device__ __forceinline__ void dec_chunk(const KArgs &a, gin_t rowp, gout_t orow, int co0, int bx,
                                           uint32_t bpx)
 {
     uint32_t px[K];
@@ -295,12 +312,12 @@ __device__ __forceinline__ void dec_chunk(const KArgs &a, const uint32_t *rowp, 
 }
 
 template <int ROUND, int FMT, int F, int HOLD, bool SROWS, int K, bool NT, bool CHECK>
-__device__ __forceinline__ void dec_rows(const KArgs &a, const uint32_t *in, uint32_t *out, int co0, int bx,
+__device__ __forceinline__ void dec_rows(const KArgs &a, gin_t in, gout_t out, int co0, int bx,
                                          int ro0, int row_step)
 {
     for (int ro = ro0; ro < a.Ho; ro += row_step) {
-        const uint32_t *rowp = in + (int64_t)(ro * F) * a.ip;
-        uint32_t *orow = out + (int64_t)ro * a.op;
+        const gin_t rowp = in + (int64_t)(ro * F) * a.ip;
+        const gout_t orow = out + (int64_t)ro * a.op;
         if (SROWS) {
             const int r = ro >> a.sc_shift;                               // chroma row = ro / F
             if (r & a.vmask) {                                            // odd chroma row of 4:x:0
@@ -321,8 +338,8 @@ __global__ void __launch_bounds__(256) k_dec(KArgs a)
     const int bx = a.bdx;
     const int cbase = blockIdx.x * (bx * K);
     const int co0 = cbase + threadIdx.x;
-    const uint32_t *in = frame_in(a);
-    uint32_t *out = frame_out(a);
+    const gin_t in = frame_in(a);
+    const gout_t out = frame_out(a);
     const int row_step = a.row_step;
     const int ro0 = blockIdx.y * a.bdy + threadIdx.y;
     // two separate row loops (the condition is uniform over the block) so that the fast path keeps
@@ -346,12 +363,12 @@ __global__ void __launch_bounds__(256) k_dec2v(KArgs a)
     const int nx = a.Wo / OPL;                          // lanes per row (W % 8 == 0 -> exact)
     const int x = blockIdx.x * a.bdx + threadIdx.x;
     if (x >= nx) return;
-    const uint32_t *in = frame_in(a);
-    uint32_t *out = frame_out(a);
+    const gin_t in = frame_in(a);
+    const gout_t out = frame_out(a);
     const int row_step = a.row_step;
     for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += row_step) {
-        const uint32_t *rowp = in + (int64_t)(ro * 2) * a.ip + (int64_t)x * (OPL * 2);
-        uint32_t *op = out + (int64_t)ro * a.op + (int64_t)x * OPL;
+        const gin_t rowp = in + (int64_t)(ro * 2) * a.ip + (int64_t)x * (OPL * 2);
+        const gout_t op = out + (int64_t)ro * a.op + (int64_t)x * OPL;
         if (VAR == 1) {
             const u32x4 p = ld4<NT>(rowp);
             const ChromaTerm t0 = chroma_term<ROUND, FMT>(p.x, a.mcb, a.mcr);
@@ -387,7 +404,7 @@ __global__ void __launch_bounds__(256) k_dec2v(KArgs a)
 // ------------------------------------------------------------------------------------------------
 // arithmetic + stores of one already loaded 4 x TH tile
 template <int ROUND, int FMT, int F, int HH, int VV, bool NT, int TH>
-__device__ __forceinline__ void avg_tile(const KArgs &a, const u32x4 (&p)[TH], uint32_t *out, int tr, int x4)
+__device__ __forceinline__ void avg_tile(const KArgs &a, const u32x4 (&p)[TH], gout_t out, int tr, int x4)
 {
     constexpr int NLOG = (HH == 4 ? 2 : HH == 2 ? 1 : 0) + (VV == 2 ? 1 : 0);
     constexpr int FLOG2 = (F == 8 ? 6 : F == 4 ? 4 : F == 2 ? 2 : 0);
@@ -440,7 +457,7 @@ __device__ __forceinline__ void avg_tile(const KArgs &a, const u32x4 (&p)[TH], u
                     sr = ((sr + ((FF * FF) >> 1)) >> FLOG2) & a.mcr;
                     o[oj] = finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr));
                 }
-                uint32_t *op = out + (int64_t)(tr * NOY + oi) * a.op + x4 * NOX;
+                const gout_t op = out + (int64_t)(tr * NOY + oi) * a.op + x4 * NOX;
                 if (NOX == 4) { const u32x4 ov = {o[0], o[1 % NOX], o[2 % NOX], o[3 % NOX]}; st4<NT>(op, ov); }
                 else if (NOX == 2) { const u32x2 ov = {o[0], o[1 % NOX]}; st2<NT>(op, ov); }
                 else st1<NT>(op, o[0]);
@@ -475,8 +492,8 @@ __global__ void __launch_bounds__(256) k_avg(KArgs a)
     const int W4 = a.W >> 2;
     const int x0 = blockIdx.x * (a.bdx * TILES) + threadIdx.x;
     if (x0 >= W4) return;
-    const uint32_t *in = frame_in(a);
-    uint32_t *out = frame_out(a);
+    const gin_t in = frame_in(a);
+    const gout_t out = frame_out(a);
     const int ntr = a.H / TH;
     for (int tr = blockIdx.y * a.bdy + threadIdx.y; tr < ntr; tr += a.row_step) {
         u32x4 p[TILES][TH];
@@ -501,8 +518,8 @@ __global__ void __launch_bounds__(256) k_avg_generic(KArgs a)
     pin_args(a);
     const int co = blockIdx.x * a.bdx + threadIdx.x;
     if (co >= a.Wo) return;
-    const uint32_t *in = frame_in(a);
-    uint32_t *out = frame_out(a);
+    const gin_t in = frame_in(a);
+    const gout_t out = frame_out(a);
     const int h = a.hmask + 1, v = a.vmask + 1, f = a.f;
     const int nlog = (h == 4 ? 2 : h == 2 ? 1 : 0) + (v == 2 ? 1 : 0);
     const int flog2 = 2 * a.sc_shift;
@@ -542,8 +559,8 @@ __global__ void __launch_bounds__(256) k_generic(KArgs a)
     pin_args(a);
     const int co = blockIdx.x * a.bdx + threadIdx.x;
     if (co >= a.Wo) return;
-    const uint32_t *in = frame_in(a);
-    uint32_t *out = frame_out(a);
+    const gin_t in = frame_in(a);
+    const gout_t out = frame_out(a);
     const int row_step = a.row_step;
     for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += row_step) {
         const int64_t y_idx = (int64_t)(ro * a.f) * a.ip + co * a.f;
