@@ -10,24 +10,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_bench_all_configs.jsonl")
-    print("| # | workload (`config.workload`) | launch (`config.launch`) | kernel | Mpx/s (input) | µs / step | algorithmic GB/s | % HBM roofline | "
-          "same steps through the direct engine: stream-ordered µs / step (%) · host-ordered µs / step (%) |")
-    print("|---|---|---|---|---|---|---|---|---|")
+    print("| # | workload (`config.workload`) | launch (`config.launch`) | kernel | Mpx/s (input) | µs / step (launches per step) | µs / launch (HIP events) | "
+          "algorithmic GB/s | % HBM roofline | same launches through the direct engine: stream-ordered µs / launch (%) · host-ordered µs / launch (%) |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     for i, l in enumerate(open(path), 1):
         r = json.loads(l)
         c, rf = r["config"], r["roofline"]
         wl = c["workload"].replace(", FLOOR_HW", "").replace(" ARGB", "")
         d, h = r.get("direct_dispatch"), r.get("direct_host_ordered")
+        lps = c.get("launches_per_step", 1)
+        per = lambda o: 1e3 * o["ms_per_step"] / lps                                                # µs per launch of a side object
         if d and "ms_per_step" in d:
-            dd = f"{1e3 * d['ms_per_step']:.2f} ({100 * d['roofline_frac_rank0']:.1f} %)"
+            dd = f"{per(d):.2f} ({100 * d['roofline_frac_rank0']:.1f} %)"
             ho = d.get("host_ordered")
-            dd += f" · {1e3 * ho['ms_per_step']:.2f} ({100 * ho['roofline_frac_rank0']:.1f} %)" if ho else ""
+            dd += f" · {per(ho):.2f} ({100 * ho['roofline_frac_rank0']:.1f} %)" if ho else ""
         elif h:
-            dd = f"(this line) · {1e3 * h['ms_per_step']:.2f} ({100 * h['roofline_frac_rank0']:.1f} %)"
+            dd = f"(this line) · {per(h):.2f} ({100 * h['roofline_frac_rank0']:.1f} %)"
         else:
             dd = "—"
-        print(f"| {i} | {wl} | {c['launch']} | `{c['kernel']}` | {r['value']:,.0f} | {1e3 * r['ms_per_step']:.2f} | {rf['achieved']:,.0f} | "
-              f"{100 * rf['frac']:.1f} | {dd} |")
+        print(f"| {i} | {wl} | {c['launch']} | `{c['kernel']}` | {r['value']:,.0f} | {1e3 * r['ms_per_step']:.2f} ({lps}) | "
+              f"{1e3 * rf['kernel_ms_avg']:.2f} | {rf['achieved']:,.0f} | {100 * rf['frac']:.1f} | {dd} |")
     first = json.loads(open(path).readline())
     cb = first.get("cpu_baseline")
     if cb:
