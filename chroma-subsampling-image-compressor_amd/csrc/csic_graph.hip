@@ -30,15 +30,18 @@
 //    loaded executables (hsa_ven_amd_loader_iterate_executables) under the name hipKernelNameRefByPtr reports.
 //    These queues are not HIP streams.  csic_frame_graph_submit / _wait order a submission by the host.
 //    csic_frame_graph_launch(graph, stream) orders it with a HIP stream ON THE DEVICE: the signals are HIP "signal
-//    memory" (the value word of an HSA signal), so the stream opens a gate packet at the head of every queue with
-//    hipStreamWriteValue64 and waits for the closing packets with hipStreamWaitValue64 -- asynchronous, no host
-//    round trip (see `stream_ordered` below; without that runtime feature launch() degrades to sync + submit + wait).
+//    memory" (the value word of an HSA signal): a one-wave gate kernel at the head of every queue spins on the gate
+//    word, one hand-off kernel on the stream opens it and spins on the queues' done words (k_gate_wait / k_handoff
+//    below; the command-processor form -- gate barrier packets, hipStreamWriteValue64 / hipStreamWaitValue64 -- stays
+//    selectable) -- asynchronous, no host round trip (see `stream_ordered` below; without that runtime feature
+//    launch() degrades to sync + submit + wait).
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 #include <hsa/hsa_ven_amd_loader.h>
 #include <hsa/amd_hsa_signal.h>
 
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -222,10 +225,63 @@ static hsa_status_t executable_cb(hsa_executable_t ex, void *data)
     return s->found ? HSA_STATUS_INFO_BREAK : HSA_STATUS_SUCCESS;
 }
 
-// Kernel object of the HIP kernel behind host stub `fn` on the engine's device.
-static int engine_kernel(DirectEngine *e, KernelFn fn, KernelInfo *out)
+// ------------------------------------------------------------------------------------------------
+// Device-polled hand-off between a HIP stream and the engine's queues.
+// A cross-queue dependency expressed as an AQL barrier packet (or hipStreamWaitValue64) is resolved by the command
+// processor POLLING the signal: about 10 us per hop on this part (tools/probe_stream_launch.py: a stream-ordered launch
+// cost 17 + 10 * queues us more than the same submission ordered by the host).  A wave that polls the same word reacts
+// within a microsecond.  So a stream-ordered launch is: a one-wave k_gate_wait at the head of every queue (dispatched when
+// the host submits; spins until the gate word is 0), and ONE one-wave k_handoff on the launch stream, which opens the gate
+// when the stream reaches it and then spins until every queue's closing packet has zeroed its done word.
+// Both spins are bounded (s_memrealtime, 100 MHz): on a timeout the kernel sets the graph's error word and returns, so no
+// wave outlives `timeout_ticks` whatever happens on the other side.
+// ------------------------------------------------------------------------------------------------
+struct GateArgs {
+    const uint64_t *gate;
+    uint32_t *err;
+    uint64_t timeout_ticks;
+};
+struct HandoffArgs {
+    uint64_t *gate;
+    const uint64_t *done[MAX_QUEUES];
+    uint32_t *err;
+    uint64_t timeout_ticks;
+    int32_t nq;
+};
+
+__device__ __forceinline__ uint64_t poll64(const uint64_t *p)
 {
-    const void *key = reinterpret_cast<const void *>(fn);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void __launch_bounds__(64) k_gate_wait(GateArgs a)
+{
+    if (threadIdx.x != 0) return;
+    const uint64_t t0 = wall_clock64();
+    while (poll64(a.gate) != 0) {
+        if (wall_clock64() - t0 > a.timeout_ticks) { __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_handoff(HandoffArgs a)
+{
+    if (threadIdx.x != 0) return;
+    // everything the stream did before this kernel is visible to the queues' kernels once they see the gate open
+    __hip_atomic_store(a.gate, (uint64_t)0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t t0 = wall_clock64();
+    for (int j = 0; j < a.nq; ++j) {
+        while (poll64(a.done[j]) != 0) {
+            if (wall_clock64() - t0 > a.timeout_ticks) { __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);      // (the next packet on the stream carries its own acquire as well)
+}
+
+// Kernel object of the HIP kernel behind host stub `key` on the engine's device.
+static int engine_kernel(DirectEngine *e, const void *key, size_t min_kernarg, KernelInfo *out)
+{
     auto it = e->kernels.find(key);
     if (it != e->kernels.end()) { *out = it->second; return CSIC_OK; }
     hipFuncAttributes attr;
@@ -244,8 +300,8 @@ static int engine_kernel(DirectEngine *e, KernelFn fn, KernelInfo *out)
     if (!s.found) return set_error(CSIC_EHIP, "kernel %s not found among the loaded executables", name);
     if (s.group != 0 || s.priv != 0)
         return set_error(CSIC_EHIP, "kernel %s uses LDS/scratch (%u/%u B): not dispatchable by the direct engine", name, s.group, s.priv);
-    if (s.info.kernarg_size < sizeof(KArgs))
-        return set_error(CSIC_EHIP, "kernel %s: kernarg segment %u B smaller than KArgs (%zu B)", name, s.info.kernarg_size, sizeof(KArgs));
+    if (s.info.kernarg_size < min_kernarg)
+        return set_error(CSIC_EHIP, "kernel %s: kernarg segment %u B smaller than its arguments (%zu B)", name, s.info.kernarg_size, min_kernarg);
     e->kernels[key] = s.info;
     *out = s.info;
     return CSIC_OK;
@@ -313,7 +369,15 @@ struct csic_frame_graph {
     hsa_signal_t gate[DIRECT_SLOTS] = {};
     hipEvent_t consumed[DIRECT_SLOTS] = {};                 // recorded on the launch stream behind its waits
     bool slot_on_stream[DIRECT_SLOTS] = {};
+    // device-polled hand-off (see k_gate_wait / k_handoff): default for stream-ordered launches; CSIC_DIRECT_HANDOFF=cp in the
+    // environment keeps the command processor's barrier packets + hipStreamWriteValue64 / hipStreamWaitValue64 (A/B)
+    bool kernel_handoff = false;
+    KernelInfo gate_kernel;
+    void *d_gateargs = nullptr;                             // DIRECT_SLOTS kernarg blocks for k_gate_wait, device memory
+    uint32_t *err_word = nullptr;                           // pinned host memory: bit 0 = a gate wait timed out, bit 1 = a hand-off did
+    uint64_t timeout_ticks = 0;
 };
+constexpr size_t GATEARG_STRIDE = 512;
 
 static void graph_free(csic_frame_graph *g)
 {
@@ -323,6 +387,8 @@ static void graph_free(csic_frame_graph *g)
     if (g->fork) (void)hipEventDestroy(g->fork);
     for (auto s : g->streams) if (s) (void)hipStreamSynchronize(s);        // pooled: not destroyed here
     if (g->d_kernarg) (void)hipFree(g->d_kernarg);
+    if (g->d_gateargs) (void)hipFree(g->d_gateargs);
+    if (g->err_word) (void)hipHostFree(g->err_word);
     if (g->d_tables) (void)hipFree(g->d_tables);
     if (g->have_signals && !g->stream_ordered)
         for (int s = 0; s < DIRECT_SLOTS; ++s)
@@ -413,7 +479,7 @@ static int build_direct(csic_frame_graph *g, csic_plan *plan, const void *const 
     for (int k = 0; k < n; ++k) {
         st = prepare_launch(plan, d_in[k], d_out[k], 1, 0, 0, &descs[k]);
         if (st != CSIC_OK) return st;
-        st = engine_kernel(e, descs[k].fn, &infos[k]);
+        st = engine_kernel(e, reinterpret_cast<const void *>(descs[k].fn), sizeof(KArgs), &infos[k]);
         if (st != CSIC_OK) return st;
         const size_t need = (infos[k].kernarg_size + 255u) & ~size_t(255);
         if (need > stride) stride = need;
@@ -468,6 +534,41 @@ static int build_direct(csic_frame_graph *g, csic_plan *plan, const void *const 
         }
         g->stream_ordered = true;
         g->have_signals = true;
+        const char *mode = std::getenv("CSIC_DIRECT_HANDOFF");
+        if (!(mode && std::strcmp(mode, "cp") == 0)) {
+            // device-polled hand-off; any failure to set it up leaves the command-processor path in place
+            double ms = 30000.0;
+            if (const char *t = std::getenv("CSIC_DIRECT_TIMEOUT_MS")) { const double v = std::atof(t); if (v >= 1.0) ms = v; }
+            g->timeout_ticks = (uint64_t)(ms * 1.0e5);                           // s_memrealtime counts at 100 MHz
+            KernelInfo gi;
+            void *ew = nullptr;
+            if (engine_kernel(e, reinterpret_cast<const void *>(k_gate_wait), sizeof(GateArgs), &gi) == CSIC_OK &&
+                gi.kernarg_size <= GATEARG_STRIDE && hipHostMalloc(&ew, 64, hipHostMallocDefault) == hipSuccess) {
+                g->err_word = static_cast<uint32_t *>(ew);
+                *g->err_word = 0;
+                std::vector<uint8_t> blocks;
+                try { blocks.assign(GATEARG_STRIDE * DIRECT_SLOTS, 0); } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
+                for (int s = 0; s < DIRECT_SLOTS; ++s) {
+                    GateArgs ga{g->sigmem[s][0], g->err_word, g->timeout_ticks};
+                    uint8_t *b = blocks.data() + (size_t)s * GATEARG_STRIDE;
+                    std::memcpy(b, &ga, sizeof ga);
+                    const size_t hid = (sizeof(GateArgs) + 7) & ~size_t(7);
+                    if (hid + 18 <= gi.kernarg_size) {
+                        const uint32_t bc[3] = {1, 1, 1};
+                        const uint16_t gs[3] = {64, 1, 1};
+                        std::memcpy(b + hid, bc, 12);
+                        std::memcpy(b + hid + 12, gs, 6);
+                    }
+                }
+                HIP_TRY(hipMalloc(&g->d_gateargs, blocks.size()));
+                HIP_TRY(hipMemcpy(g->d_gateargs, blocks.data(), blocks.size(), hipMemcpyHostToDevice));
+                g->gate_kernel = gi;
+                g->kernel_handoff = true;
+            } else {
+                (void)hipGetLastError();
+                clear_error();
+            }
+        }
         return CSIC_OK;
     }
     for (int s = 0; s < DIRECT_SLOTS; ++s)
@@ -493,6 +594,9 @@ static int wait_slot(csic_frame_graph *g, int64_t ticket)
     if (g->slot_on_stream[slot]) {              // a stream-ordered launch: done when the stream has passed its waits
         HIP_TRY(hipEventSynchronize(g->consumed[slot]));
         g->slot_on_stream[slot] = false;
+        if (g->err_word && *g->err_word)
+            return set_error(CSIC_EHIP, "direct dispatch: a stream-ordered launch timed out waiting for %s (flags %u)",
+                             (*g->err_word & 1u) ? "its gate" : "its queues", *g->err_word);
         return CSIC_OK;
     }
     // done[slot][0] is completed by queue 0's closing packet, which depends on every other queue's closing signal
@@ -512,8 +616,8 @@ static int direct_wait(csic_frame_graph *g, int64_t ticket)
     return CSIC_OK;
 }
 
-// gated = stream-ordered: every queue starts with a barrier-AND packet on the slot's gate signal, which the launch
-// stream opens with hipStreamWriteValue64 once its earlier work is done.
+// gated = stream-ordered: every queue starts with a gate on the slot's gate word -- a k_gate_wait dispatch (device-polled
+// hand-off) or a barrier-AND packet on the gate signal -- which the launch stream opens once its earlier work is done.
 static int direct_submit(csic_frame_graph *g, int64_t *ticket, bool gated = false)
 {
     DirectEngine *e = g->eng;
@@ -525,21 +629,43 @@ static int direct_submit(csic_frame_graph *g, int64_t *ticket, bool gated = fals
     const int slot = (int)(t % DIRECT_SLOTS);
     std::lock_guard<std::mutex> lk(e->mu);
     const int nq = g->branches;                                 // this graph's queues: the engine's first `nq`
-    for (int j = 0; j < nq; ++j) hsa_signal_store_relaxed(g->done[slot][j], 1);
+    // Re-arm the slot's signals.  hsa_signal_store_* on an interrupt-capable signal also raises its event -- a KFD ioctl of
+    // several microseconds, per signal -- which nobody listens for here (the slot is idle: no waiter, no packet refers to it
+    // yet).  With HIP signal memory the value word is ours to write, so a plain store does (measured: 10 us per queue off a
+    // stream-ordered launch).
+    if (g->stream_ordered) {
+        for (int j = 0; j < nq; ++j) __atomic_store_n(g->sigmem[slot][1 + j], (uint64_t)1, __ATOMIC_RELAXED);
+        if (gated) __atomic_store_n(g->sigmem[slot][0], (uint64_t)1, __ATOMIC_RELEASE);
+    } else {
+        for (int j = 0; j < nq; ++j) hsa_signal_store_relaxed(g->done[slot][j], 1);
+    }
+    const bool kgate = gated && g->kernel_handoff;
     if (gated) {
-        hsa_signal_store_screlease(g->gate[slot], 1);
         const uint16_t h_gate = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                                 (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE);
+        const uint16_t h_kgate = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE);   // no barrier bit: it only waits
         for (int j = 0; j < nq; ++j) {
             hsa_queue_t *q = e->q[j];
             const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
             for (uint64_t spins = 0; idx + 1 - hsa_queue_load_read_index_scacquire(q) > q->size; ++spins)
                 if (spins > 2000000000ull) return set_error(CSIC_EHIP, "direct dispatch: queue %d is not draining", j);
-            auto *bp = reinterpret_cast<hsa_barrier_and_packet_t *>(static_cast<hsa_kernel_dispatch_packet_t *>(q->base_address) + (idx & (q->size - 1)));
-            std::memset(reinterpret_cast<uint8_t *>(bp) + 4, 0, sizeof *bp - 4);
-            bp->dep_signal[0] = g->gate[slot];
-            publish(bp, h_gate, 0);
-            hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)idx);
+            void *slotp = static_cast<hsa_kernel_dispatch_packet_t *>(q->base_address) + (idx & (q->size - 1));
+            if (kgate) {
+                // one wave that spins on the gate word; the first frame's barrier bit makes the queue wait for it
+                auto *kp = static_cast<hsa_kernel_dispatch_packet_t *>(slotp);
+                std::memset(reinterpret_cast<uint8_t *>(kp) + 4, 0, sizeof *kp - 4);
+                kp->workgroup_size_x = 64; kp->workgroup_size_y = 1; kp->workgroup_size_z = 1;
+                kp->grid_size_x = 64; kp->grid_size_y = 1; kp->grid_size_z = 1;
+                kp->kernel_object = g->gate_kernel.object;
+                kp->kernarg_address = static_cast<uint8_t *>(g->d_gateargs) + (size_t)slot * GATEARG_STRIDE;
+                publish(kp, h_kgate, 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
+            } else {
+                auto *bp = static_cast<hsa_barrier_and_packet_t *>(slotp);
+                std::memset(reinterpret_cast<uint8_t *>(bp) + 4, 0, sizeof *bp - 4);
+                bp->dep_signal[0] = g->gate[slot];
+                publish(bp, h_gate, 0);
+            }
+            // no doorbell of its own: the packets written next ring it past this index
         }
     }
     const uint16_t setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
@@ -582,7 +708,7 @@ static int direct_submit(csic_frame_graph *g, int64_t *ticket, bool gated = fals
                 for (uint32_t c = 0; c < nclose; ++c) {
                     auto *bp = reinterpret_cast<hsa_barrier_and_packet_t *>(&ring[(idx + nk + c) & mask]);
                     std::memset(reinterpret_cast<uint8_t *>(bp) + 4, 0, sizeof *bp - 4);
-                    if (j == 0)
+                    if (j == 0 && !kgate)                               // (k_handoff polls every queue's done word itself)
                         for (int k = 0; k < 5 && dep < nq; ++k) bp->dep_signal[k] = g->done[slot][dep++];
                     if (c + 1 == nclose) bp->completion_signal = g->done[slot][j];
                     publish(bp, h_close, 0);
@@ -681,9 +807,29 @@ int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
         }
         // Asynchronous and ordered with `stream`: the queues are armed behind a gate; the stream opens it when its
         // earlier work is done and then waits for every queue's closing packet.
+        if (g->err_word && *g->err_word)
+            return set_error(CSIC_EHIP, "direct dispatch: an earlier stream-ordered launch timed out (flags %u)", *g->err_word);
         int st = direct_submit(g, &t, true);
         if (st != CSIC_OK) return st;
         const int slot = (int)(t % DIRECT_SLOTS);
+        if (g->kernel_handoff) {
+            HandoffArgs ha{};
+            ha.gate = g->sigmem[slot][0];
+            for (int j = 0; j < g->branches; ++j) ha.done[j] = g->sigmem[slot][1 + j];
+            ha.err = g->err_word;
+            ha.timeout_ticks = g->timeout_ticks;
+            ha.nq = g->branches;
+            void *params[1] = {&ha};
+            hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(k_handoff), dim3(1), dim3(64), params, 0, stream);
+            if (e != hipSuccess) {
+                __atomic_store_n(g->sigmem[slot][0], (uint64_t)0, __ATOMIC_RELEASE);     // never leave the queues blocked
+                return set_error(CSIC_EHIP, "launching the hand-off kernel failed: %s", hipGetErrorString(e));
+            }
+            HIP_TRY(hipEventRecord(g->consumed[slot], stream));
+            g->slot_on_stream[slot] = true;
+            clear_error();
+            return CSIC_OK;
+        }
         hipError_t e = hipStreamWriteValue64(stream, g->sigmem[slot][0], 0, 0);
         if (e != hipSuccess) {
             // the queues are armed behind the gate: never leave them blocked -- open it from the host (the work then

@@ -250,10 +250,18 @@ int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *
  *                            csic_frame_graph_launch(graph, hip_stream) orders the same work with a HIP stream on
  *                            the device, asynchronously: the graph's signals are HIP "signal memory"
  *                            (hipExtMallocWithFlags(.., hipMallocSignalMemory) -- the value word of an HSA signal,
- *                            usable as hsa_signal_t in AQL barrier packets), so every queue starts with a gate
- *                            packet that `hip_stream` opens with hipStreamWriteValue64 once its earlier work is
- *                            done, and the stream then waits for every queue's closing packet with
- *                            hipStreamWaitValue64; work enqueued on `hip_stream` afterwards sees the outputs.
+ *                            usable as hsa_signal_t in AQL barrier packets and readable / writable by kernels).
+ *                            Every queue starts with a one-wave gate kernel that spins on the gate word; ONE one-wave
+ *                            hand-off kernel on `hip_stream` opens the gate when the stream reaches it and then spins
+ *                            until every queue's closing packet has zeroed its done word; work enqueued on
+ *                            `hip_stream` afterwards sees the outputs.  (A dependency resolved by the command
+ *                            processor polling a signal -- AQL barrier packets, hipStreamWaitValue64 -- costs about
+ *                            10 us per hop on this part; a polling wave reacts within a microsecond.  Both spins are
+ *                            bounded: after CSIC_DIRECT_TIMEOUT_MS (environment, default 30000) the kernel flags the
+ *                            graph and returns, and the next launch / wait of that graph reports CSIC_EHIP.
+ *                            CSIC_DIRECT_HANDOFF=cp in the environment keeps the command-processor form -- gate
+ *                            barrier packets opened by hipStreamWriteValue64, hipStreamWaitValue64 on the closing
+ *                            signal -- for comparison.)
  *                            csic_frame_graph_stream_ordered() tells whether the runtime offered this (else launch
  *                            degrades to hipStreamSynchronize + submit + wait).  A gate blocks its queues until the
  *                            stream reaches it, so do not make that stream's earlier work depend on a LATER direct
@@ -262,9 +270,9 @@ int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *
  *                            Queue count: the device runs 4 queues at once.  Host-ordered submissions are fastest
  *                            on 4 (cfg 5 frame 1.71 us, 3 queues 1.78 us); a stream-ordered launch also keeps the
  *                            launch stream's own queue busy, and with 4 + 1 active queues the hardware scheduler
- *                            time-slices them (64 frames: 370 us instead of 157 us) -- hence the default of 3.  A
- *                            stream-ordered launch costs 17-40 us of signal hand-offs (1-3 queues) on top of the
- *                            host-ordered time: record many frames per graph.
+ *                            time-slices them (64 frames: 298 us instead of 128 us) -- hence the default of 3.  A
+ *                            stream-ordered launch costs about 10 us of hand-off on top of the host-ordered time
+ *                            (17-40 us in the command-processor form): record several frames per graph.
  *
  *   CSIC_FRAME_GRAPH_FUSED   not per-frame launches at all: ONE kernel launch covers every frame (frame index on the
  *                            grid's z axis, the frame bases read from a device-resident pointer table the graph owns), so

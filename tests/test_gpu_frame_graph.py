@@ -359,3 +359,69 @@ def test_frame_graph_at_the_frame_count_limit(csic, oracle, backend):
         for k in (0, 1, 65534, 65535):
             want = oracle.process(_oparams(oracle, W, H, 2, 0, (8, 8, 8), 2), host[k * W * H:(k + 1) * W * H], form="closed")
             assert np.array_equal(d_out[k * opx:(k + 1) * opx].cpu().numpy().view(np.uint32), want.reshape(-1)), k
+
+
+@pytest.mark.parametrize("handoff", ["kernel", "cp"])
+def test_direct_launch_both_handoff_forms(csic, oracle, handoff, monkeypatch):
+    """The stream-ordered launch in its device-polled form (k_gate_wait / k_handoff, the default) and in the
+    command-processor form (CSIC_DIRECT_HANDOFF=cp: gate barrier packets, hipStreamWriteValue64 / hipStreamWaitValue64):
+    producer and consumer on the launch stream, 1-4 queues, graphs replayed back to back."""
+    import torch
+    monkeypatch.setenv("CSIC_DIRECT_HANDOFF", handoff)
+    monkeypatch.setenv("CSIC_DIRECT_TIMEOUT_MS", "5000")
+    W, H, n = 320, 64, 9
+    cp = csic.make_c_params(W, H, 2, 0, 3, 3, 2, 2, CSQ)
+    rng = np.random.default_rng(7)
+    with csic.Plan(cp, 0) as pl:
+        opx = pl.out_width * pl.out_height
+        for q in (1, 2, 3, 4):
+            d_ins = [torch.zeros(W * H, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+            d_outs = [torch.zeros(opx, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+            with csic.FrameGraph(pl, d_ins, d_outs, branches=q, backend="direct") as g:
+                if not g.stream_ordered:
+                    pytest.skip("this runtime offers no HIP signal memory")
+                rounds, kept = [], []
+                for r in range(12):                                   # no host synchronisation inside the loop
+                    src = torch.from_numpy(rng.integers(0, 2**32, size=n * W * H, dtype=np.uint32).view(np.int32)).cuda()
+                    rounds.append(src)
+                    for k in range(n):
+                        d_ins[k].copy_(src[k * W * H:(k + 1) * W * H])     # producer on the launch stream
+                    g.launch()
+                    kept.append(torch.cat(d_outs))                         # consumer on the launch stream
+                torch.cuda.synchronize()
+                for r in (0, 5, 11):
+                    host = rounds[r].cpu().numpy().view(np.uint32)
+                    got = kept[r].cpu().numpy().view(np.uint32)
+                    for k in (0, n - 1):
+                        want = oracle.process(_oparams(oracle, W, H, 2, 0, (3, 3, 2), 2), host[k * W * H:(k + 1) * W * H], form="closed")
+                        assert np.array_equal(got[k * opx:(k + 1) * opx], want.reshape(-1)), (handoff, q, r, k)
+
+
+def test_a_stalled_stream_cannot_hang_the_gate_kernels(csic, oracle, monkeypatch):
+    """The gate kernels spin only for CSIC_DIRECT_TIMEOUT_MS: with the launch stream stalled for longer than that they
+    flag the graph and let their queues go (no wave outlives the timeout), and the graph reports the timeout."""
+    import torch
+    monkeypatch.setenv("CSIC_DIRECT_HANDOFF", "kernel")
+    monkeypatch.setenv("CSIC_DIRECT_TIMEOUT_MS", "20")
+    W, H, n = 256, 32, 4
+    cp = csic.make_c_params(W, H, 2, 0, 8, 8, 8, 2, CSQ)
+    host = [oracle.synth_frame(W * H, 77 + k) for k in range(n)]
+    with csic.Plan(cp, 0) as pl:
+        d_ins = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
+        d_outs = [torch.zeros(pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+        torch.cuda.synchronize()
+        g = csic.FrameGraph(pl, d_ins, d_outs, branches=2, backend="direct")
+        try:
+            if not g.stream_ordered:
+                pytest.skip("this runtime offers no HIP signal memory")
+            torch.cuda._sleep(int(6.0e8))                              # ~0.25 s of stall on the launch stream
+            g.launch()
+            torch.cuda.synchronize()                                   # returns: nothing is left spinning
+            with pytest.raises(csic.CsicRuntimeError, match="timed out"):
+                g.launch()
+            # the frames themselves ran (unordered with the stalled stream, their inputs were ready anyway)
+            for k in range(n):
+                want = oracle.process(_oparams(oracle, W, H, 2, 0, (8, 8, 8), 2), host[k], form="closed")
+                assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(want.shape), want), k
+        finally:
+            g.close()
