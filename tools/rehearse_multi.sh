@@ -2,21 +2,25 @@
 # tools/rehearse_multi.sh [TAG] -- on the 1-GPU box: the N > 1 launcher path, twice, two ranks sharing GPU 0
 # over gloo.  Logs: gpurun_out/<TAG>_multi_rehearsal.{halo,bench}.log (copied to profiles/).
 #   (a) StripedImageCompressorTop, real HIP Plan, CUDA rows, aligned stripes + unaligned row_splits (_exchange_halo)
-#   (b) bench.py --gpus 2 --backend gloo: strong split of ONE 8192x8192 frame as `value`, weak beside it
+#   (b) bench.py --gpus $NP --backend gloo: strong split of ONE 8192x8192 frame as `value`, weak beside it
 set -o pipefail
 TAG=${1:-r02}
+NP=${2:-2}               # ranks sharing GPU 0 (4 rehearses the N = 4 path: issue = direct as the `value` path)
+SUF=""; [ "$NP" != "2" ] && SUF="_np$NP"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd "$ROOT"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
-    tools/rehearse_multi.py halo > "$OUT/${TAG}_multi_rehearsal.halo.log" 2>&1
+if [ "$NP" = "2" ]; then          # (the halo cases are written for two ranks)
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $NP --master-addr 127.0.0.1 --master-port 29517 \
+    tools/rehearse_multi.py halo > "$OUT/${TAG}_multi_rehearsal${SUF}.halo.log" 2>&1
 rc=$?
-tail -n 4 "$OUT/${TAG}_multi_rehearsal.halo.log"
+tail -n 4 "$OUT/${TAG}_multi_rehearsal${SUF}.halo.log"
 [ $rc -eq 0 ] || exit $rc
-timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 \
-    bench.py --gpus 2 --backend gloo --steps 20 --warmup 5 > "$OUT/${TAG}_multi_rehearsal.bench.log" 2>&1
+fi
+timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $NP --master-addr 127.0.0.1 --master-port 29518 \
+    bench.py --gpus $NP --backend gloo --steps 20 --warmup 5 > "$OUT/${TAG}_multi_rehearsal${SUF}.bench.log" 2>&1
 rc=$?
-tail -n 2 "$OUT/${TAG}_multi_rehearsal.bench.log"
+tail -n 2 "$OUT/${TAG}_multi_rehearsal${SUF}.bench.log"
 exit $rc
