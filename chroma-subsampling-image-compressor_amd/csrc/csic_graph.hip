@@ -43,6 +43,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <mutex>
 #include <new>
@@ -245,6 +246,8 @@ struct HandoffArgs {
     uint64_t *gate;
     const uint64_t *done[MAX_QUEUES];
     uint32_t *err;
+    uint64_t *passed;          // host-visible: the ticket + 1 of the last launch whose hand-off has finished (slot recycling)
+    uint64_t seq;
     uint64_t timeout_ticks;
     int32_t nq;
 };
@@ -272,11 +275,18 @@ __global__ void __launch_bounds__(64) k_handoff(HandoffArgs a)
     const uint64_t t0 = wall_clock64();
     for (int j = 0; j < a.nq; ++j) {
         while (poll64(a.done[j]) != 0) {
-            if (wall_clock64() - t0 > a.timeout_ticks) { __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+            if (wall_clock64() - t0 > a.timeout_ticks) {
+                __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.passed, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
             __builtin_amdgcn_s_sleep(4);
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);      // (the next packet on the stream carries its own acquire as well)
+    // the slot's words have been read for the last time: the host may re-arm them (replaces a hipEventRecord per launch,
+    // i.e. one more barrier packet on the stream between consecutive launches)
+    __hip_atomic_store(a.passed, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Kernel object of the HIP kernel behind host stub `key` on the engine's device.
@@ -375,6 +385,8 @@ struct csic_frame_graph {
     KernelInfo gate_kernel;
     void *d_gateargs = nullptr;                             // DIRECT_SLOTS kernarg blocks for k_gate_wait, device memory
     uint32_t *err_word = nullptr;                           // pinned host memory: bit 0 = a gate wait timed out, bit 1 = a hand-off did
+    uint64_t *passed_word = nullptr;                        // same allocation (+8): see HandoffArgs::passed
+    int64_t slot_ticket[DIRECT_SLOTS] = {};                 // ticket of the stream-ordered launch that last used the slot
     uint64_t timeout_ticks = 0;
 };
 constexpr size_t GATEARG_STRIDE = 512;
@@ -546,6 +558,8 @@ static int build_direct(csic_frame_graph *g, csic_plan *plan, const void *const 
                 gi.kernarg_size <= GATEARG_STRIDE && hipHostMalloc(&ew, 64, hipHostMallocDefault) == hipSuccess) {
                 g->err_word = static_cast<uint32_t *>(ew);
                 *g->err_word = 0;
+                g->passed_word = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(ew) + 8);
+                *g->passed_word = 0;
                 std::vector<uint8_t> blocks;
                 try { blocks.assign(GATEARG_STRIDE * DIRECT_SLOTS, 0); } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
                 for (int s = 0; s < DIRECT_SLOTS; ++s) {
@@ -592,7 +606,24 @@ static int wait_slot(csic_frame_graph *g, int64_t ticket)
 {
     const int slot = (int)(ticket % DIRECT_SLOTS);
     if (g->slot_on_stream[slot]) {              // a stream-ordered launch: done when the stream has passed its waits
-        HIP_TRY(hipEventSynchronize(g->consumed[slot]));
+        if (g->kernel_handoff) {
+            // k_handoff publishes ticket + 1 when it has read the slot's words for the last time
+            const uint64_t want = (uint64_t)g->slot_ticket[slot] + 1;
+            timespec t0{}, now{};
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (uint64_t spins = 0; __atomic_load_n(g->passed_word, __ATOMIC_ACQUIRE) < want; ++spins) {
+                if (spins < 2000) continue;                                     // ~ a few microseconds of pure spinning
+                if ((spins & 63) == 0) {
+                    clock_gettime(CLOCK_MONOTONIC, &now);
+                    const double el = (double)(now.tv_sec - t0.tv_sec) + 1e-9 * (double)(now.tv_nsec - t0.tv_nsec);
+                    if (el > 2.0e-8 * (double)g->timeout_ticks + 5.0)          // both device spins have timed out by then
+                        return set_error(CSIC_EHIP, "direct dispatch: launch %lld did not pass its hand-off in time", (long long)g->slot_ticket[slot]);
+                    if (el > 2.0e-4) { const timespec nap{0, 20000}; nanosleep(&nap, nullptr); }
+                }
+            }
+        } else {
+            HIP_TRY(hipEventSynchronize(g->consumed[slot]));
+        }
         g->slot_on_stream[slot] = false;
         if (g->err_word && *g->err_word)
             return set_error(CSIC_EHIP, "direct dispatch: a stream-ordered launch timed out waiting for %s (flags %u)",
@@ -817,6 +848,8 @@ int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
             ha.gate = g->sigmem[slot][0];
             for (int j = 0; j < g->branches; ++j) ha.done[j] = g->sigmem[slot][1 + j];
             ha.err = g->err_word;
+            ha.passed = g->passed_word;
+            ha.seq = (uint64_t)t + 1;
             ha.timeout_ticks = g->timeout_ticks;
             ha.nq = g->branches;
             void *params[1] = {&ha};
@@ -825,7 +858,7 @@ int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
                 __atomic_store_n(g->sigmem[slot][0], (uint64_t)0, __ATOMIC_RELEASE);     // never leave the queues blocked
                 return set_error(CSIC_EHIP, "launching the hand-off kernel failed: %s", hipGetErrorString(e));
             }
-            HIP_TRY(hipEventRecord(g->consumed[slot], stream));
+            g->slot_ticket[slot] = t;
             g->slot_on_stream[slot] = true;
             clear_error();
             return CSIC_OK;
