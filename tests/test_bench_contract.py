@@ -90,3 +90,50 @@ def test_headline_step_is_a_batch_of_per_frame_launches():
     bench = _load_bench()
     assert bench.DEFAULT_BATCH == {"cfg4": 64}
     assert bench.GRAPH_CAP <= 4096
+
+
+def test_run_steps_issues_exactly_the_requested_launches():
+    """The timed region must hold EXACTLY K steps = K * batch launches, whatever mix of whole-graph replays, the shorter
+    graph for the ragged end and eager launches run_steps picks (no GPU: the graphs and the step function are counters)."""
+    bench = _load_bench()
+
+    class FakeGraph:
+        def __init__(self, n, log):
+            self.nframes, self.log = n, log
+
+        def launch(self, stream):
+            self.log.append(self.nframes)
+
+    for total, cap in ((1280, 4096), (3200, 4096), (5000, 4096), (8192, 4096), (4097, 4096), (7, 4096), (64, 16), (100, 16)):
+        log = []
+        wl = bench.Workload.__new__(bench.Workload)
+        wl.stream = None
+        glen = min(total, cap)
+        wl.graph_len = glen
+        wl.step_graph = FakeGraph(glen, log)
+        rem = total % glen
+        wl.rem_graph = FakeGraph(rem, log) if rem else None
+        wl.step = lambda i: (log.append(1), 0)[1]
+        assert wl.run_steps(0, total) == 0
+        assert sum(log) == total, (total, cap, log[:8])
+        assert all(n in (glen, rem, 1) for n in log)
+        # the timed launches come from graphs only (a Python loop cannot feed 3 us launches): no eager launch when total is
+        # what the graphs were built for
+        assert 1 not in log or glen == 1 or rem == 1
+        # warm-up and pre-warm counts are arbitrary: still exact
+        for count in (0, 1, 5 * 64, glen - 1, glen + 3):
+            log.clear()
+            wl.run_steps(3, count)
+            assert sum(log) == count, (total, cap, count)
+    # without a graph every launch is eager
+    log = []
+    wl = bench.Workload.__new__(bench.Workload)
+    wl.step_graph, wl.rem_graph, wl.graph_len = None, None, 0
+    wl.step = lambda i: (log.append(i), 0)[1]
+    wl.run_steps(10, 25)
+    assert log == list(range(10, 35))
+
+
+def test_step_defaults_follow_the_batch():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "args.steps = max(1, 3200 // args.batch)" in src and "KL = K * args.batch" in src
