@@ -848,10 +848,21 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
     const int rows = (fam == FAM_F1X4) ? g.H : (fam == FAM_AVG) ? g.H / (g.f > g.v ? g.f : g.v) : g.Ho;
     const int lanes_x = (units + kpl - 1) / kpl;
     int tpb = 256;
-    if (pl->block_threads == 64 || pl->block_threads == 128 || pl->block_threads == 256) tpb = pl->block_threads;
+    const bool forced = pl->block_threads == 64 || pl->block_threads == 128 || pl->block_threads == 256;
+    const int hold = (fam == FAM_DEC && dec_hold > 0) ? dec_hold : 1;
+    if (forced) tpb = pl->block_threads;
     else if (fam == FAM_DEC && nframes == 1 && units % kpl == 0 && lanes_x % 128 == 0 &&
              4ll * ((int64_t)g.W * g.Ho + (int64_t)g.Wo * g.Ho) >= (64ll << 20))
         tpb = 128;
+    else if (fam == FAM_DEC && units % kpl == 0 && lanes_x >= 16 && lanes_x <= 128) {
+        // Narrow rows (a row needs at most two waves): one-wave blocks, when the row tiles into them, beat blocks that stack
+        // several rows -- batched launches, profiles/r02_probe_block_batched.log: 512x512 f=2 69.1 -> 73.5 %, f=8 69.3 -> 73.2,
+        // 1024x1024 f=8 66.8 -> 78.3, 1920x1080 f=4 74.1 -> 75.6, f=8 71.0 -> 73.5; rows that do not tile (1000x1000 f=2: 125
+        // lanes) lose (70.8 -> 63.4) and keep the default, as do rows of fewer than 16 lanes (128x128 f=4/8: -1 %).
+        bool tiles = (lanes_x & (lanes_x - 1)) == 0;                       // 16, 32, 64, 128
+        for (int w = 64; !tiles && w >= 48; --w) tiles = lanes_x % w == 0 && w % hold == 0;
+        if (tiles) tpb = 64;
+    }
     int bx = pow2_ceil(lanes_x);
     if (bx > tpb) bx = tpb;
     if (bx < 1) bx = 1;
@@ -860,7 +871,6 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
         // their last chunk on the bounds-checked path.  A block width that divides the row exactly keeps
         // every block on the straight-line path (4K f=2: 70 % -> 80 % of HBM peak).  The width only has to
         // be a multiple of the lane-hold distance so that a DPP hold group never straddles two rows.
-        const int hold = dec_hold > 0 ? dec_hold : 1;
         if (lanes_x <= tpb) {
             if (lanes_x % hold == 0) bx = lanes_x;
         } else {
