@@ -270,8 +270,8 @@ int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *
  *                            Queue count: the device runs 4 queues at once.  Host-ordered submissions are fastest
  *                            on 4 (cfg 5 frame 1.71 us, 3 queues 1.78 us); a stream-ordered launch also keeps the
  *                            launch stream's own queue busy, and with 4 + 1 active queues the hardware scheduler
- *                            time-slices them (64 frames: 298 us instead of 128 us) -- hence the default of 3.  A
- *                            stream-ordered launch costs about 10 us of hand-off on top of the host-ordered time
+ *                            time-slices them (64 frames: 250 us instead of 126 us) -- hence the default of 3.  A
+ *                            stream-ordered launch costs about 8 us of hand-off on top of the host-ordered time
  *                            (17-40 us in the command-processor form): record several frames per graph.
  *
  *   CSIC_FRAME_GRAPH_FUSED   not per-frame launches at all: ONE kernel launch covers every frame (frame index on the

@@ -45,6 +45,25 @@ __global__ void __launch_bounds__(256) k_lane4(const uint32_t *in, uint32_t *out
     } else if ((px[0] ^ px[1] ^ px[2] ^ px[3]) == 0x12345678u) sink[0] = px[0];
 }
 
+// lane4 loads, then a transposition through LDS so that every lane stores 16 contiguous bytes (a wave writes 1 KiB contiguous
+// instead of four separate 256-byte chunks): does the store granularity matter for the read/write mix?
+__global__ void __launch_bounds__(256) k_lane4_lds16(const uint32_t *in, uint32_t *out, int W, int Wo, int f, int64_t frame_px, int64_t oframe_px)
+{
+    __shared__ uint32_t tile[1024];
+    const uint32_t *rp = in + blockIdx.z * frame_px + (int64_t)(blockIdx.y * f) * W;
+    const int bd = blockDim.x;
+    const int co0 = blockIdx.x * (bd * 4) + threadIdx.x;
+    uint32_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) px[k] = __builtin_nontemporal_load(rp + (int64_t)(co0 + k * bd) * f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[threadIdx.x + k * bd] = px[k] * 3u + 1u;
+    __syncthreads();
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(&tile[4 * threadIdx.x]);
+    uint32_t *op = out + blockIdx.z * oframe_px + (int64_t)blockIdx.y * Wo + blockIdx.x * (bd * 4);
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(op) + threadIdx.x);
+}
+
 int main()
 {
     hipEvent_t e0, e1;
@@ -90,6 +109,8 @@ int main()
                 run(nm, rd, [&](int i) { hipLaunchKernelGGL((k_lane4<false>), dim3(Wo / 4 / bt4, live, sh.frames), dim3(bt4), 0, 0, in[i % sh.nring], out[i % sh.nring], sink, sh.W, Wo, f, frame_px, (int64_t)Wo * live); });
                 snprintf(nm, sizeof nm, "%s f=%d lane4 + stores (rate over read+write)", sh.name, f);
                 run(nm, rd + wr, [&](int i) { hipLaunchKernelGGL((k_lane4<true>), dim3(Wo / 4 / bt4, live, sh.frames), dim3(bt4), 0, 0, in[i % sh.nring], out[i % sh.nring], sink, sh.W, Wo, f, frame_px, (int64_t)Wo * live); });
+                snprintf(nm, sizeof nm, "%s f=%d lane4 + LDS transpose + 16-byte stores", sh.name, f);
+                run(nm, rd + wr, [&](int i) { hipLaunchKernelGGL(k_lane4_lds16, dim3(Wo / 4 / bt4, live, sh.frames), dim3(bt4), 0, 0, in[i % sh.nring], out[i % sh.nring], sh.W, Wo, f, frame_px, (int64_t)Wo * live); });
             }
         }
         for (int i = 0; i < sh.nring; ++i) { CK(hipFree(in[i])); CK(hipFree(out[i])); }
