@@ -31,6 +31,7 @@ bench)
   $B --config cfg3 --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config sq1000 --order scq --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config sq1024 --order scq --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  $B --config sq1000 --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1      # k_dec on the SAME 1000x1000 frames (chroma before spatial)
   wc -l "$J"
   ;;
 profile)
