@@ -269,7 +269,8 @@ class Workload:
         self.graph_len = 0
         if self.issue != "serial" and not self.per_frame_graph and fps == 1 and args.streams <= 1:
             total = max(1, args.steps * args.batch)                      # launches in the timed region
-            self.graph_len = glen = min(total, GRAPH_CAP)
+            # fused: ONE kernel launch per step over the step's frames (a pointer table over the ring buffers)
+            self.graph_len = glen = min(total, GRAPH_CAP) if backend != "fused" else max(1, min(args.batch, total))
             br = (args.direct_queues if backend == "direct" else args.step_chains) or None
             self.step_graph = csic.FrameGraph(self.plan, [self.ins[j % nring] for j in range(glen)],
                                               [self.outs[j % nring] for j in range(glen)], backend=backend, branches=br)
@@ -626,6 +627,15 @@ def main(argv=None):
         return res
 
     sides = {}
+    if args.batch > 1 and head["fps"] == 1 and args.streams <= 1 and not args.pitch_pad and issue != "fused" and not args.no_side:
+        # the same steps with ONE launch per step instead of one launch per frame: what batching the frames of a step buys
+        # (not the headline: configs[3] names single frames, and a frame per launch is what a stream of arriving frames allows)
+        try:
+            sides["one_launch_per_step"] = side(headline_mode, "fused")
+            sides["one_launch_per_step"]["note"] = (f"{args.batch} frames per launch (CSIC_FRAME_GRAPH_FUSED over the same ring buffers); "
+                                                    "ms_per_launch and roofline_frac_rank0 are per FRAME")
+        except csic.CsicRuntimeError as exc:
+            sides["one_launch_per_step"] = {"unavailable": str(exc)}
     can_graph = args.streams <= 1 and (head["fps"] == 1 or (args.per_frame_graph and head["fps"] > 1))
     if world > 1:
         # the other scaling mode, issued the same way as the headline
