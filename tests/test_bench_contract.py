@@ -137,3 +137,25 @@ def test_run_steps_issues_exactly_the_requested_launches():
 def test_step_defaults_follow_the_batch():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "args.steps = max(1, 3200 // args.batch)" in src and "KL = K * args.batch" in src
+
+
+def test_baseline_md_table_is_the_rendered_artifact():
+    """BASELINE.md section 3 must be, line for line, what tools/render_baseline_table.py renders from the committed
+    profiles/r02_bench_all_configs.jsonl -- a number in the document that is not in the artefact is a stale number."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "render_baseline_table.py")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    doc = open(os.path.join(ROOT, "BASELINE.md"), encoding="utf-8").read()
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) >= 19
+    for l in lines:
+        assert l in doc, "BASELINE.md is out of date with profiles/r02_bench_all_configs.jsonl: " + l[:120]
+
+
+def test_committed_traffic_matches_the_checked_out_sources():
+    """The committed PMC traffic entries were measured on the kernel sources of this checkout (otherwise bench.py would
+    report traffic: null on the driver's run)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from srchash import kernel_source_sha256
+    have = kernel_source_sha256(ROOT)
+    ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert ent["cfg4"]["source_sha256"] == have, "re-run tools/r02_artifacts.sh profile + tools/collect_artifacts.py"
