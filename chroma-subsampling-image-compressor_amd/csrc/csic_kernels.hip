@@ -859,9 +859,11 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
         // several rows -- batched launches, profiles/r02_probe_block_batched.log: 512x512 f=2 69.1 -> 73.5 %, f=8 69.3 -> 73.2,
         // 1024x1024 f=8 66.8 -> 78.3, 1920x1080 f=4 74.1 -> 75.6, f=8 71.0 -> 73.5; rows that do not tile (1000x1000 f=2: 125
         // lanes) lose (70.8 -> 63.4) and keep the default, as do rows of fewer than 16 lanes (128x128 f=4/8: -1 %).
-        bool tiles = (lanes_x & (lanes_x - 1)) == 0;                       // 16, 32, 64, 128
+        // With f >= 4, rows of fewer than 64 lanes fit one wave whatever their width (640x480 f=4, 40 lanes: 74.1 -> 77.7 %;
+        // 352x288 f=4 s>c: 62.0 -> 72.4 %); at f = 2 that loses (352x288, 44 lanes: 70.5 -> 59.3 %) and only powers of two qualify.
+        bool tiles = (g.f >= 4 && lanes_x < 64) || (lanes_x & (lanes_x - 1)) == 0;       // 16, 32, 64, 128; any < 64 for f >= 4
         for (int w = 64; !tiles && w >= 48; --w) tiles = lanes_x % w == 0 && w % hold == 0;
-        if (tiles) tpb = 64;
+        if (tiles && (lanes_x >= 64 || lanes_x % hold == 0)) tpb = 64;
     }
     int bx = pow2_ceil(lanes_x);
     if (bx > tpb) bx = tpb;
@@ -876,6 +878,16 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
         } else {
             for (int m = (lanes_x + tpb - 1) / tpb; m <= lanes_x / (tpb / 2); ++m)
                 if (lanes_x % m == 0 && (lanes_x / m) % hold == 0) { bx = lanes_x / m; break; }
+        }
+    }
+    if (fam == FAM_F1X4 && !forced) {
+        // One 16-byte load and store per lane: this kernel lives on the wave launch rate, so waves that exit at once (the idle
+        // part of a block's last chunk) or run partly filled cost in proportion.  1280-wide rows are 320 lanes: [256][64 + 192
+        // idle] runs at 61 %, 5 x 64 lanes (four rows to a block) at 78 % (profiles/r02_probe_block_batched_video.log).
+        if (lanes_x % 64 == 0) {
+            for (int w : {256, 192, 128, 64}) if (lanes_x % w == 0) { bx = w; break; }
+        } else if (lanes_x <= 256) {
+            bx = lanes_x;                                      // one partly filled wave per row instead of idle ones
         }
     }
     const int by = tpb / bx > 0 ? tpb / bx : 1;

@@ -13,10 +13,10 @@ dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream()
 sh = C.c_void_p(st.cuda_stream)
 SHAPES = [(128, 128), (512, 512), (1000, 1000), (1024, 1024), (1920, 1080), (3840, 2160), (7680, 4320)]
-only = sys.argv[1:]            # optional: WxH filters
+only = sys.argv[1:]            # optional: WxH ... (any sizes; default: the list above)
+if only:
+    SHAPES = [tuple(int(v) for v in o.split("x")) for o in only]
 for (W, H) in SHAPES:
-    if only and f"{W}x{H}" not in only:
-        continue
     for f in (1, 2, 4, 8):
         for order in ((3, 1, 2), (1, 3, 2)):
             if f == 1 and order != (3, 1, 2):
