@@ -460,6 +460,10 @@ def main(argv=None):
     ap.add_argument("--direct", action="store_true",
                     help="N=1: also time the same K steps with issue=direct and report them beside the headline as `direct_dispatch` "
                          "(off by default at N=1 so that `rocprofv3 --stats` of the default command sees only the serial launches)")
+    ap.add_argument("--one-launch", action="store_true",
+                    help="N=1: also time the same K steps with ONE launch per step over its frames (the fused frame graph) and report "
+                         "them as `one_launch_per_step` (always on at N>1 and with --stripe-of; off by default at N=1 so that "
+                         "`rocprofv3 --stats` of the default command sees only the per-frame launches of the headline kernel)")
     ap.add_argument("--no-side", action="store_true",
                     help="N>1: skip the side measurement of the other issue mode (`hip_streams`)")
     ap.add_argument("--streams", type=int, default=1,
@@ -627,7 +631,8 @@ def main(argv=None):
         return res
 
     sides = {}
-    if args.batch > 1 and head["fps"] == 1 and args.streams <= 1 and not args.pitch_pad and issue != "fused" and not args.no_side:
+    if args.batch > 1 and head["fps"] == 1 and args.streams <= 1 and not args.pitch_pad and issue != "fused" and not args.no_side \
+            and (world > 1 or args.stripe_of > 1 or args.one_launch):
         # the same steps with ONE launch per step instead of one launch per frame: what batching the frames of a step buys
         # (not the headline: configs[3] names single frames, and a frame per launch is what a stream of arriving frames allows)
         try:

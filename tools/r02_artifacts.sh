@@ -19,7 +19,7 @@ B="python bench.py --no-cpu-baseline --direct"
 case "$STAGE" in
 bench)
   J=$OUT/bench_all_configs.jsonl; : > "$J"
-  python bench.py --cpu-budget 5 --direct >> "$J" 2> "$OUT/bench.err" || exit 1
+  python bench.py --cpu-budget 5 --direct --one-launch >> "$J" 2> "$OUT/bench.err" || exit 1
   for c in cfg5 8k_444_f1 8k_420_f1 avg_8k_420_sf2 avg_4k_420_sf4 cfg2 cfg3; do $B --config $c >> "$J" 2>> "$OUT/bench.err" || exit 1; done
   BN="python bench.py --no-cpu-baseline"
   $BN --config cfg5 --per-frame-graph --issue hip --graph-branches 1 --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
@@ -71,7 +71,7 @@ stripes)
   # what ONE rank of the N-GPU strong-scaling run does, measured alone on this GPU (bench.py --stripe-of N)
   J=$OUT/bench_stripe_of.jsonl; : > "$J"
   # with the driver's own flags (K = 20 steps, W = 5), N = 1 first, then one rank's share of N = 2, 4, 8
-  python bench.py --steps 20 --warmup 5 --no-cpu-baseline >> "$J" 2>> "$OUT/bench.err" || exit 1
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --one-launch >> "$J" 2>> "$OUT/bench.err" || exit 1
   for n in 2 4 8; do python bench.py --stripe-of $n --steps 20 --warmup 5 --no-cpu-baseline >> "$J" 2>> "$OUT/bench.err" || exit 1; done
   python - "$J" <<'PY'
 import json, sys
