@@ -515,6 +515,40 @@ def test_video_widths_tile_exactly(csic, oracle, W, H):
             assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H, a, b, f, op)
 
 
+@pytest.mark.parametrize("W,H,f,orders", [
+    (512, 64, 2, (CSQ, (1, 3, 2))),      # 64 lanes: one-wave blocks, one row each
+    (512, 64, 8, (CSQ, (1, 2, 3))),      # 16 lanes: four rows to a one-wave block
+    (1024, 48, 8, (CSQ, (1, 3, 2))),     # 32 lanes
+    (1024, 32, 2, (CSQ, (1, 3, 2))),     # 128 lanes: two one-wave blocks per row
+    (1920, 40, 4, (CSQ, (1, 3, 2))),     # 120 lanes = 2 x 60
+    (1920, 48, 8, (CSQ, (1, 2, 3))),     # 60 lanes
+    (640, 48, 4, (CSQ, (1, 3, 2))),      # 40 lanes: under 64, f >= 4
+    (352, 32, 4, (CSQ, (1, 3, 2))),      # 22 lanes
+    (352, 32, 2, (CSQ, (1, 3, 2))),      # 44 lanes at f = 2: keeps the 256-thread geometry
+    (1280, 24, 1, (CSQ,)),               # k_f1x4, 320 lanes = 5 x 64, four rows to a block
+    (352, 24, 1, (CSQ,)),                # k_f1x4, 88 lanes: block width = row
+    (720, 24, 1, (CSQ,)),                # k_f1x4, 180 lanes
+    (3840, 16, 1, (CSQ,)),               # k_f1x4, 960 lanes = 5 x 192
+])
+def test_block_geometry_rules(csic, oracle, W, H, f, orders):
+    """The shapes that trigger each block-geometry rule of prepare_common (one-wave blocks for narrow rows, whole-wave
+    blocks for k_f1x4), single frames and batches of three, every chroma mode: bit-exact against the oracle."""
+    import torch
+    n = 3
+    host_in = oracle.synth_frame(n * W * H, 31 * W + f)
+    for order in orders:
+        for (a, b) in ((2, 0), (4, 4), (1, 1), (2, 2)):
+            op = _oparams(oracle, W, H, a, b, (5, 4, 3), f, order)
+            want = [oracle.process(op, host_in[k * W * H:(k + 1) * W * H], form="closed") for k in range(n)]
+            with _plan(csic, W, H, a, b, (5, 4, 3), f, order) as pl:
+                assert np.array_equal(pl.process_host(host_in[:W * H]), want[0]), (pl.kernel_name, W, H, a, b, f, order)
+                d_out = pl.process_device(torch.from_numpy(host_in.view(np.int32)).cuda(), nframes=n)
+                torch.cuda.synchronize()
+                got = d_out.cpu().numpy().view(np.uint32)
+                for k in range(n):
+                    assert np.array_equal(got[k], want[k]), (pl.kernel_name, W, H, a, b, f, order, k)
+
+
 # ---- launch-geometry edges ---------------------------------------------------------------------------------
 def test_batched_launch_every_kernel_family(csic, oracle):
     """Several frames per launch (frame index on grid z) for every kernel family, including narrow frames
