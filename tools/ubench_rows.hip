@@ -64,6 +64,21 @@ __global__ void __launch_bounds__(256) k_lane4_lds16(const uint32_t *in, uint32_
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(op) + threadIdx.x);
 }
 
+// f >= 4: every lane loads the 16 bytes that start at its live pixel (the live pixel + 3 dead ones; at f = 4 the wave's loads are
+// dense), 4 such loads per lane spaced by the block width, dense 4-byte stores: the shipped shape with a wider request
+__global__ void __launch_bounds__(256) k_lane16_w(const uint32_t *in, uint32_t *out, int W, int Wo, int f, int64_t frame_px, int64_t oframe_px)
+{
+    const uint32_t *rp = in + blockIdx.z * frame_px + (int64_t)(blockIdx.y * f) * W;
+    const int bd = blockDim.x;
+    const int co0 = blockIdx.x * (bd * 4) + threadIdx.x;
+    u32x4 px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) px[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rp + (int64_t)(co0 + k * bd) * f));
+    uint32_t *op = out + blockIdx.z * oframe_px + (int64_t)blockIdx.y * Wo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(px[k].x * 3u + 1u, op + co0 + k * bd);
+}
+
 int main()
 {
     hipEvent_t e0, e1;
@@ -109,6 +124,10 @@ int main()
                 run(nm, rd, [&](int i) { hipLaunchKernelGGL((k_lane4<false>), dim3(Wo / 4 / bt4, live, sh.frames), dim3(bt4), 0, 0, in[i % sh.nring], out[i % sh.nring], sink, sh.W, Wo, f, frame_px, (int64_t)Wo * live); });
                 snprintf(nm, sizeof nm, "%s f=%d lane4 + stores (rate over read+write)", sh.name, f);
                 run(nm, rd + wr, [&](int i) { hipLaunchKernelGGL((k_lane4<true>), dim3(Wo / 4 / bt4, live, sh.frames), dim3(bt4), 0, 0, in[i % sh.nring], out[i % sh.nring], sink, sh.W, Wo, f, frame_px, (int64_t)Wo * live); });
+                if (f >= 4) {
+                    snprintf(nm, sizeof nm, "%s f=%d 16-byte loads at the live pixel + 4-byte stores", sh.name, f);
+                    run(nm, rd + wr, [&](int i) { hipLaunchKernelGGL(k_lane16_w, dim3(Wo / 4 / bt4, live, sh.frames), dim3(bt4), 0, 0, in[i % sh.nring], out[i % sh.nring], sh.W, Wo, f, frame_px, (int64_t)Wo * live); });
+                }
                 snprintf(nm, sizeof nm, "%s f=%d lane4 + LDS transpose + 16-byte stores", sh.name, f);
                 run(nm, rd + wr, [&](int i) { hipLaunchKernelGGL(k_lane4_lds16, dim3(Wo / 4 / bt4, live, sh.frames), dim3(bt4), 0, 0, in[i % sh.nring], out[i % sh.nring], sh.W, Wo, f, frame_px, (int64_t)Wo * live); });
             }
