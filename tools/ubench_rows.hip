@@ -79,6 +79,34 @@ __global__ void __launch_bounds__(256) k_lane16_w(const uint32_t *in, uint32_t *
     for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(px[k].x * 3u + 1u, op + co0 + k * bd);
 }
 
+// load cache policies for the shipped shape (f = 2 only): POL 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 nt sc1, 5 nt sc0 sc1, 6 sc0
+template <int POL> __device__ __forceinline__ uint32_t ld_pol(const uint32_t *p)
+{
+    uint32_t v;
+    if (POL == 1) asm volatile("global_load_dword %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+    else if (POL == 2) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    else if (POL == 3) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    else if (POL == 4) asm volatile("global_load_dword %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    else if (POL == 5) asm volatile("global_load_dword %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    else if (POL == 6) asm volatile("global_load_dword %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+    else asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int POL>
+__global__ void __launch_bounds__(256) k_lane4_pol(const uint32_t *in, uint32_t *out, int W, int Wo, int f, int64_t frame_px, int64_t oframe_px)
+{
+    const uint32_t *rp = in + blockIdx.z * frame_px + (int64_t)(blockIdx.y * f) * W;
+    const int bd = blockDim.x;
+    const int co0 = blockIdx.x * (bd * 4) + threadIdx.x;
+    uint32_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) px[k] = ld_pol<POL>(rp + (int64_t)(co0 + k * bd) * f);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t *op = out + blockIdx.z * oframe_px + (int64_t)blockIdx.y * Wo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(px[k] * 3u + 1u, op + co0 + k * bd);
+}
+
 int main()
 {
     hipEvent_t e0, e1;
@@ -124,6 +152,12 @@ int main()
                 run(nm, rd, [&](int i) { hipLaunchKernelGGL((k_lane4<false>), dim3(Wo / 4 / bt4, live, sh.frames), dim3(bt4), 0, 0, in[i % sh.nring], out[i % sh.nring], sink, sh.W, Wo, f, frame_px, (int64_t)Wo * live); });
                 snprintf(nm, sizeof nm, "%s f=%d lane4 + stores (rate over read+write)", sh.name, f);
                 run(nm, rd + wr, [&](int i) { hipLaunchKernelGGL((k_lane4<true>), dim3(Wo / 4 / bt4, live, sh.frames), dim3(bt4), 0, 0, in[i % sh.nring], out[i % sh.nring], sink, sh.W, Wo, f, frame_px, (int64_t)Wo * live); });
+                if (f == 2 && sh.W == 8192) {
+                    const char *pn[7] = {"plain", "nt", "sc1", "sc0 sc1", "sc1 nt", "sc0 sc1 nt", "sc0"};
+                    auto go = [&](int pol, auto kern) { snprintf(nm, sizeof nm, "%s f=2 lane4 loads [%s] + nt stores", sh.name, pn[pol]);
+                        run(nm, rd + wr, [&](int i) { hipLaunchKernelGGL(kern, dim3(Wo / 4 / bt4, live, sh.frames), dim3(bt4), 0, 0, in[i % sh.nring], out[i % sh.nring], sh.W, Wo, f, frame_px, (int64_t)Wo * live); }); };
+                    go(0, k_lane4_pol<0>); go(1, k_lane4_pol<1>); go(2, k_lane4_pol<2>); go(3, k_lane4_pol<3>); go(4, k_lane4_pol<4>); go(5, k_lane4_pol<5>); go(6, k_lane4_pol<6>);
+                }
                 if (f >= 4) {
                     snprintf(nm, sizeof nm, "%s f=%d 16-byte loads at the live pixel + 4-byte stores", sh.name, f);
                     run(nm, rd + wr, [&](int i) { hipLaunchKernelGGL(k_lane16_w, dim3(Wo / 4 / bt4, live, sh.frames), dim3(bt4), 0, 0, in[i % sh.nring], out[i % sh.nring], sh.W, Wo, f, frame_px, (int64_t)Wo * live); });
