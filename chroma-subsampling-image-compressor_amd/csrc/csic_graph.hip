@@ -246,7 +246,7 @@ struct HandoffArgs {
     uint64_t *gate;
     const uint64_t *done[MAX_QUEUES];
     uint32_t *err;
-    uint64_t *passed;          // host-visible: the ticket + 1 of the last launch whose hand-off has finished (slot recycling)
+    uint64_t *passed;          // host-visible, one word per slot: ticket + 1 of the launch whose hand-off has finished (slot recycling)
     uint64_t seq;
     uint64_t timeout_ticks;
     int32_t nq;
@@ -385,7 +385,8 @@ struct csic_frame_graph {
     KernelInfo gate_kernel;
     void *d_gateargs = nullptr;                             // DIRECT_SLOTS kernarg blocks for k_gate_wait, device memory
     uint32_t *err_word = nullptr;                           // pinned host memory: bit 0 = a gate wait timed out, bit 1 = a hand-off did
-    uint64_t *passed_word = nullptr;                        // same allocation (+8): see HandoffArgs::passed
+    uint64_t *passed_word = nullptr;                        // same allocation (+64): DIRECT_SLOTS words, see HandoffArgs::passed --
+                                                            // per slot, so that launches of one graph on different streams may finish in any order
     int64_t slot_ticket[DIRECT_SLOTS] = {};                 // ticket of the stream-ordered launch that last used the slot
     uint64_t timeout_ticks = 0;
 };
@@ -555,11 +556,11 @@ static int build_direct(csic_frame_graph *g, csic_plan *plan, const void *const 
             KernelInfo gi;
             void *ew = nullptr;
             if (engine_kernel(e, reinterpret_cast<const void *>(k_gate_wait), sizeof(GateArgs), &gi) == CSIC_OK &&
-                gi.kernarg_size <= GATEARG_STRIDE && hipHostMalloc(&ew, 64, hipHostMallocDefault) == hipSuccess) {
+                gi.kernarg_size <= GATEARG_STRIDE && hipHostMalloc(&ew, 64 + 8 * DIRECT_SLOTS, hipHostMallocDefault) == hipSuccess) {
                 g->err_word = static_cast<uint32_t *>(ew);
                 *g->err_word = 0;
-                g->passed_word = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(ew) + 8);
-                *g->passed_word = 0;
+                g->passed_word = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(ew) + 64);
+                for (int s = 0; s < DIRECT_SLOTS; ++s) g->passed_word[s] = 0;
                 std::vector<uint8_t> blocks;
                 try { blocks.assign(GATEARG_STRIDE * DIRECT_SLOTS, 0); } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
                 for (int s = 0; s < DIRECT_SLOTS; ++s) {
@@ -611,7 +612,7 @@ static int wait_slot(csic_frame_graph *g, int64_t ticket)
             const uint64_t want = (uint64_t)g->slot_ticket[slot] + 1;
             timespec t0{}, now{};
             clock_gettime(CLOCK_MONOTONIC, &t0);
-            for (uint64_t spins = 0; __atomic_load_n(g->passed_word, __ATOMIC_ACQUIRE) < want; ++spins) {
+            for (uint64_t spins = 0; __atomic_load_n(&g->passed_word[slot], __ATOMIC_ACQUIRE) != want; ++spins) {
                 if (spins < 2000) continue;                                     // ~ a few microseconds of pure spinning
                 if ((spins & 63) == 0) {
                     clock_gettime(CLOCK_MONOTONIC, &now);
@@ -848,7 +849,7 @@ int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
             ha.gate = g->sigmem[slot][0];
             for (int j = 0; j < g->branches; ++j) ha.done[j] = g->sigmem[slot][1 + j];
             ha.err = g->err_word;
-            ha.passed = g->passed_word;
+            ha.passed = &g->passed_word[slot];
             ha.seq = (uint64_t)t + 1;
             ha.timeout_ticks = g->timeout_ticks;
             ha.nq = g->branches;

@@ -890,6 +890,11 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
             bx = lanes_x;                                      // one partly filled wave per row instead of idle ones
         }
     }
+    if (fam == FAM_AVG && !forced && lanes_x % 64 == 0 && lanes_x > 256 && lanes_x <= 512 && lanes_x % 256 != 0) {
+        // the same for k_avg on rows of at most two blocks: 1280-wide f = 4 / 8 (320 lanes) 64 / 61 % -> 80 % with blocks of whole
+        // waves that tile the row (profiles/r02_probe_block_avg.log)
+        for (int w : {192, 128, 64}) if (lanes_x % w == 0) { bx = w; break; }
+    }
     const int by = tpb / bx > 0 ? tpb / bx : 1;
     d->block = dim3(bx, by, 1);
     unsigned gx = (unsigned)((lanes_x + bx - 1) / bx);

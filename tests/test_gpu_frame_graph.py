@@ -425,3 +425,34 @@ def test_a_stalled_stream_cannot_hang_the_gate_kernels(csic, oracle, monkeypatch
                 assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(want.shape), want), k
         finally:
             g.close()
+
+
+def test_one_direct_graph_launched_on_two_streams(csic, oracle, monkeypatch):
+    """Launches of ONE direct graph on two streams: their hand-offs finish in whatever order the streams allow (here stream A is
+    stalled first), and more launches follow than there are slots -- the per-slot 'passed' words let the host recycle each slot
+    when ITS launch has passed, not when a later one has."""
+    import torch
+    monkeypatch.setenv("CSIC_DIRECT_HANDOFF", "kernel")
+    monkeypatch.setenv("CSIC_DIRECT_TIMEOUT_MS", "8000")
+    W, H, n = 256, 32, 5
+    cp = csic.make_c_params(W, H, 2, 0, 8, 8, 8, 2, CSQ)
+    host = [oracle.synth_frame(W * H, 300 + k) for k in range(n)]
+    with csic.Plan(cp, 0) as pl:
+        d_ins = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
+        d_outs = [torch.zeros(pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with csic.FrameGraph(pl, d_ins, d_outs, branches=2, backend="direct") as g:
+            if not g.stream_ordered:
+                pytest.skip("this runtime offers no HIP signal memory")
+            with torch.cuda.stream(sa):
+                torch.cuda._sleep(int(1.0e8))                          # ~50 ms: A's launch passes long after it was submitted
+                g.launch(sa)
+            for i in range(40):                                        # 40 more launches over 16 slots, alternating streams
+                g.launch(sb if i % 3 else sa)
+            sa.synchronize()
+            sb.synchronize()
+            g.wait()
+        for k in range(n):
+            want = oracle.process(_oparams(oracle, W, H, 2, 0, (8, 8, 8), 2), host[k], form="closed")
+            assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(want.shape), want), k
