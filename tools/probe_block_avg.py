@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""tools/probe_block_avg.py -- block sizes for the AVG extension kernels on batched launches across frame sizes (does k_avg need the
-whole-wave block rule k_f1x4 got?  yes, for 1280-wide rows at f = 4 / 8 -- noted in DESIGN.md section 9, not applied yet)."""
+"""tools/probe_block_avg.py -- block sizes for the AVG extension kernels on batched launches across frame sizes (did k_avg need the
+whole-wave block rule k_f1x4 got?  yes, for 1280-wide rows at f = 4 / 8: t0 = the rule in place, t256 = the geometry before)."""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
