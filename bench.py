@@ -603,12 +603,15 @@ def main(argv=None):
             "fps": wl.fps, "launches_per_replay": wl.launches_per_step}
     head_host_ordered = None
     if issue == "direct" and (wl.step_graph is not None or wl.per_frame_graph):
-        elh, nsteps = host_ordered_direct(wl, KL, torch, dist, world, args.backend, dev)
-        pxh = allsum(float(wl.in_px) * wl.fps * nsteps)
-        head_host_ordered = {"value": round(pxh / elh / 1e6, 1), "ms_per_step": round(elh * 1e3 / nsteps * args.batch, 5),
-                             "steps": nsteps / args.batch, "ms_per_launch": round(elh * 1e3 / nsteps, 5),
-                             "roofline_frac_rank0": round(wl.alg_bytes * wl.launches_per_step * nsteps / elh / 1e9 / HBM_PEAK_GBS, 4),
-                             "how": "the headline's graphs through csic_frame_graph_submit/_wait: no gate, no stream waits, host wall clock"}
+        try:                                                            # a side measurement: it must not cost the headline line
+            elh, nsteps = host_ordered_direct(wl, KL, torch, dist, world, args.backend, dev)
+            pxh = allsum(float(wl.in_px) * wl.fps * nsteps)
+            head_host_ordered = {"value": round(pxh / elh / 1e6, 1), "ms_per_step": round(elh * 1e3 / nsteps * args.batch, 5),
+                                 "steps": nsteps / args.batch, "ms_per_launch": round(elh * 1e3 / nsteps, 5),
+                                 "roofline_frac_rank0": round(wl.alg_bytes * wl.launches_per_step * nsteps / elh / 1e9 / HBM_PEAK_GBS, 4),
+                                 "how": "the headline's graphs through csic_frame_graph_submit/_wait: no gate, no stream waits, host wall clock"}
+        except Exception as exc:                                        # noqa: BLE001
+            head_host_ordered = {"unavailable": f"{type(exc).__name__}: {exc}"}
     wl.close()
 
     def side(scaling, how):
@@ -631,38 +634,43 @@ def main(argv=None):
         return res
 
     sides = {}
+
+    def safe_side(key, scaling, how, fallback_key=None):
+        """A side measurement must never cost the headline line: whatever goes wrong in it (a backend the runtime refuses, an
+        allocation, a timeout) is recorded in its object and the run goes on.  (Every rank takes the same path through here; a
+        failure on ONE rank only would leave the others in a collective, exactly as it would without this.)"""
+        try:
+            sides[key] = side(scaling, how)
+        except Exception as exc:                                   # noqa: BLE001 -- by design, see above
+            sides[fallback_key or key] = {"unavailable": f"{type(exc).__name__}: {exc}"}
+            try:
+                torch.cuda.synchronize(dev)
+                torch.cuda.empty_cache()
+            except Exception:
+                pass
+
     if args.batch > 1 and head["fps"] == 1 and args.streams <= 1 and not args.pitch_pad and issue != "fused" and not args.no_side \
             and (world > 1 or args.stripe_of > 1 or args.one_launch):
         # the same steps with ONE launch per step instead of one launch per frame: what batching the frames of a step buys
         # (not the headline: configs[3] names single frames, and a frame per launch is what a stream of arriving frames allows)
-        try:
-            sides["one_launch_per_step"] = side(headline_mode, "fused")
+        safe_side("one_launch_per_step", headline_mode, "fused")
+        if "value" in sides["one_launch_per_step"]:
             sides["one_launch_per_step"]["note"] = (f"{args.batch} frames per launch (CSIC_FRAME_GRAPH_FUSED over the same ring buffers); "
                                                     "ms_per_launch and roofline_frac_rank0 are per FRAME")
-        except csic.CsicRuntimeError as exc:
-            sides["one_launch_per_step"] = {"unavailable": str(exc)}
     can_graph = args.streams <= 1 and (head["fps"] == 1 or (args.per_frame_graph and head["fps"] > 1))
     if world > 1:
         # the other scaling mode, issued the same way as the headline
-        sides["weak" if headline_mode == "strong" else "strong"] = side("weak" if headline_mode == "strong" else "strong", issue)
+        other_mode = "weak" if headline_mode == "strong" else "strong"
+        safe_side(other_mode, other_mode, issue)
         if can_graph and not args.no_side:
             other_issue = "hip" if issue == "direct" else "direct"
-            try:
-                sides["hip_streams" if other_issue == "hip" else "direct_dispatch"] = side(headline_mode, other_issue)
-            except csic.CsicRuntimeError as exc:
-                sides["direct_dispatch"] = {"unavailable": str(exc)}
+            safe_side("hip_streams" if other_issue == "hip" else "direct_dispatch", headline_mode, other_issue)
     elif args.stripe_of > 1 and can_graph and not args.no_side:
         other_issue = "hip" if issue == "direct" else "direct"
-        try:
-            sides["hip_streams" if other_issue == "hip" else "direct_dispatch"] = side(headline_mode, other_issue)
-        except csic.CsicRuntimeError as exc:
-            sides["direct_dispatch"] = {"unavailable": str(exc)}
-        sides["serial_launches"] = side(headline_mode, "serial")
+        safe_side("hip_streams" if other_issue == "hip" else "direct_dispatch", headline_mode, other_issue)
+        safe_side("serial_launches", headline_mode, "serial")
     elif args.direct and can_graph and issue != "direct":
-        try:
-            sides["direct_dispatch"] = side(headline_mode, "direct")
-        except csic.CsicRuntimeError as exc:
-            sides["direct_dispatch"] = {"unavailable": str(exc)}
+        safe_side("direct_dispatch", headline_mode, "direct")
 
     if rank == 0:
         traffic, traffic_note = load_traffic(args.config, head["kernel"], world)

@@ -24,7 +24,7 @@ def main():
             dd = f"{per(d):.2f} ({100 * d['roofline_frac_rank0']:.1f} %)"
             ho = d.get("host_ordered")
             dd += f" · {per(ho):.2f} ({100 * ho['roofline_frac_rank0']:.1f} %)" if ho else ""
-        elif h:
+        elif h and "ms_per_step" in h:
             dd = f"(this line) · {per(h):.2f} ({100 * h['roofline_frac_rank0']:.1f} %)"
         else:
             dd = "—"
