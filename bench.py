@@ -565,7 +565,20 @@ def main(argv=None):
             wl.close()
             issue, issue_note = "hip", "direct dispatch unavailable on some rank; all ranks use issue=hip"
             wl = Workload(args, csic, torch, dev, dev_index, world, rank, headline_mode, issue)
-    elapsed, kern_ms_avg = timed_run(wl, args, torch, dist, world, args.backend, dev)
+    try:
+        elapsed, kern_ms_avg = timed_run(wl, args, torch, dist, world, args.backend, dev)
+    except csic.CsicRuntimeError as exc:
+        # the launch engine failed while running (e.g. a hand-off timeout): measure with hipGraph chains rather than not at all
+        if issue != "direct":
+            raise
+        issue_note = f"direct dispatch failed during the run ({exc}); re-measured with issue=hip"
+        try:
+            wl.close()
+        except Exception:
+            pass
+        issue = "hip"
+        wl = Workload(args, csic, torch, dev, dev_index, world, rank, headline_mode, issue)
+        elapsed, kern_ms_avg = timed_run(wl, args, torch, dist, world, args.backend, dev)
     total_px = allsum(float(wl.in_px) * wl.fps * KL)               # real per-rank pixel counts, summed
     value = total_px / elapsed / 1e6
     achieved = wl.alg_bytes / (kern_ms_avg * 1e-3) / 1e9
