@@ -13,14 +13,14 @@ OK = 0
 EINVAL_NULL, EINVAL_DIMS, EINVAL_FACTOR, EINVAL_CHROMA_A, EINVAL_CHROMA_B = -1, -2, -3, -4, -5
 EINVAL_BITS, EINVAL_OP_PERMUTATION, EINVAL_ROUNDING, EINVAL_FORMAT = -6, -7, -8, -9
 EINVAL_NOT_DIVISIBLE, EINVAL_SAMPLING, EINVAL_STRIPE, EINVAL_SIZE = -10, -11, -12, -13
-ENODEVICE, EHIP, ENOMEM = -20, -21, -22
+ENODEVICE, EHIP, ENOMEM, ECAPTURE = -20, -21, -22, -23
 EIO, EFORMAT = -30, -31
 
 OP_NOOP, OP_SPATIAL, OP_QUANT, OP_CHROMA = 0, 1, 2, 3
 ROUND_FLOOR_HW, ROUND_TRUNC_SW = 0, 1
 FMT_ARGB8888, FMT_YCBCR888X = 0, 1
 TUNE_VARIANT, TUNE_FORCE_GENERIC, TUNE_NONTEMPORAL, TUNE_NO_VECTOR, TUNE_BLOCK_THREADS = 1, 2, 3, 4, 5
-FRAME_GRAPH_HIP, FRAME_GRAPH_DIRECT, FRAME_GRAPH_FUSED = 0, 1, 2
+FRAME_GRAPH_HIP, FRAME_GRAPH_DIRECT, FRAME_GRAPH_FUSED, FRAME_GRAPH_AUTO = 0, 1, 2, 3
 FRAME_GRAPH_DEFAULT_BRANCHES, FRAME_GRAPH_DEFAULT_QUEUES = 4, 3
 PIPELINE_STAGED, PIPELINE_ZERO_COPY = 0, 1
 
@@ -35,7 +35,7 @@ class IllegalArgumentException(ValueError):
 
 
 class CsicRuntimeError(RuntimeError):
-    """HIP / device failures (CSIC_ENODEVICE, CSIC_EHIP, CSIC_ENOMEM)."""
+    """HIP / device failures (CSIC_ENODEVICE, CSIC_EHIP, CSIC_ENOMEM, CSIC_ECAPTURE)."""
 
     def __init__(self, status: int, message: str):
         super().__init__(message)
@@ -94,6 +94,7 @@ PROTOTYPES = {
     "csic_frame_graph_submit": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "csic_frame_graph_wait": (C.c_int, [C.c_void_p, C.c_int64]),
     "csic_frame_graph_backend": (C.c_int, [C.c_void_p]),
+    "csic_frame_graph_launch_branches": (C.c_int, [C.c_void_p]),
     "csic_frame_graph_stream_ordered": (C.c_int, [C.c_void_p]),
     "csic_frame_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "csic_frame_graph_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

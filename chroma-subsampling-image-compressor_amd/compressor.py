@@ -130,18 +130,22 @@ class FrameGraph:
 
     `d_ins[k]` / `d_outs[k]` are CUDA tensors holding frame k's W*H input pixels / receiving its Wo*Ho output
     pixels; they may live anywhere on the plan's device (views into one big tensor, or separate allocations).
+    backend "auto" (default; csic_frame_graph_create): the library's choice -- today always "fused"; `backend` then names
+    what was picked.
     backend "hip": `branches` hipGraph chains, launch(stream) is asynchronous and ordered with the stream.
     backend "direct": AQL packets without barrier bits on the library's own user-mode queues (`branches` =
     queues); submit() starts immediately and returns a ticket, wait() blocks the host; launch(stream) is
     asynchronous and ordered with the stream on the device when `stream_ordered` (HIP signal memory shared with
-    the queues), else the synchronous composition stream-sync + submit + wait.
+    the queues), else the synchronous composition stream-sync + submit + wait.  launch() never uses more than 3 queues
+    (`launch_branches`), whatever `branches` says: a fourth beside the launch stream's own queue gets time-sliced; it
+    cannot be captured into a hipGraph (CsicRuntimeError, CSIC_ECAPTURE).
     backend "fused": not per-frame launches -- one kernel launch over all frames through a device-resident pointer
     table (frames in separate buffers at the speed of the contiguous batched launch); launch(stream) is an ordinary
     asynchronous launch."""
 
-    BACKENDS = {"hip": N.FRAME_GRAPH_HIP, "direct": N.FRAME_GRAPH_DIRECT, "fused": N.FRAME_GRAPH_FUSED}
+    BACKENDS = {"hip": N.FRAME_GRAPH_HIP, "direct": N.FRAME_GRAPH_DIRECT, "fused": N.FRAME_GRAPH_FUSED, "auto": N.FRAME_GRAPH_AUTO}
 
-    def __init__(self, plan: Plan, d_ins, d_outs, branches=None, backend: str = "hip"):
+    def __init__(self, plan: Plan, d_ins, d_outs, branches=None, backend: str = "auto"):
         n = len(d_ins)
         if n != len(d_outs) or n == 0:
             raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: need as many output as input frames (> 0)")
@@ -163,6 +167,10 @@ class FrameGraph:
         nf, nb = C.c_int32(), C.c_int32()
         N.check(N.lib().csic_frame_graph_count(self._h, C.byref(nf), C.byref(nb)))
         self.nframes, self.branches = nf.value, nb.value
+        resolved = N.lib().csic_frame_graph_backend(self._h)
+        self.requested_backend = backend
+        self.backend = next(k for k, v in self.BACKENDS.items() if v == resolved)
+        self.launch_branches = N.lib().csic_frame_graph_launch_branches(self._h)
         self.stream_ordered = bool(N.lib().csic_frame_graph_stream_ordered(self._h))
 
     def launch(self, stream=None) -> None:

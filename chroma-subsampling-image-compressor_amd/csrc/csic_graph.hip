@@ -41,6 +41,7 @@
 #include <hsa/amd_hsa_signal.h>
 
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
@@ -84,6 +85,12 @@ struct DirectEngine {
     std::mutex mu;                              // serialises submissions (ring reservations stay contiguous per queue)
     std::map<const void *, KernelInfo> kernels; // host stub address -> kernel object
     int refs = 0;
+    // A submission that failed AFTER some of its packets were published (a ring that stopped draining between two chunks)
+    // leaves queues behind that nobody can complete: the engine is marked failed, every later submission on this device
+    // returns its message instead of queueing behind the hole, and the engine (queues, and the device memory its packets
+    // refer to) is leaked rather than destroyed under packets that may still run.
+    bool failed = false;
+    std::string failure;
 };
 
 static std::mutex g_engines_mu;
@@ -189,6 +196,7 @@ static void engine_release(DirectEngine *e)
     std::lock_guard<std::mutex> lk(g_engines_mu);
     if (--e->refs > 0) return;
     g_engines.erase(e->device);
+    if (e->failed) return;                      // leaked on purpose: its queues may still hold packets (see DirectEngine::failed)
     engine_free(e);
 }
 
@@ -347,6 +355,7 @@ using namespace csic;
 // the graph object
 // ------------------------------------------------------------------------------------------------
 constexpr int DIRECT_SLOTS = 16;               // submissions that may be outstanding per DIRECT graph
+constexpr int MAX_STREAM_ORDERED_QUEUES = 3;   // see csic_frame_graph::lpackets
 
 struct csic_frame_graph {
     int device = 0;
@@ -364,7 +373,15 @@ struct csic_frame_graph {
     // DIRECT backend
     DirectEngine *eng = nullptr;
     void *d_kernarg = nullptr;
-    std::vector<hsa_kernel_dispatch_packet_t> packets[MAX_QUEUES];   // templates, header left INVALID
+    std::vector<hsa_kernel_dispatch_packet_t> packets[MAX_QUEUES];   // templates, header left INVALID: frame k on queue k % branches
+    // The same frames dealt over the first `lbranches` = min(branches, MAX_STREAM_ORDERED_QUEUES) queues, built only when that
+    // is fewer than `branches`: a stream-ordered launch keeps the launch stream's own hardware queue busy (its hand-off kernel
+    // runs for as long as the frames do), and with 4 library queues beside it the scheduler time-slices (cfg 5, 64 frames:
+    // 250 us instead of 126 us) -- so csic_frame_graph_launch never uses more than 3, whatever `branches` asked for.
+    std::vector<hsa_kernel_dispatch_packet_t> lpackets[MAX_QUEUES];
+    int32_t lbranches = 0;
+    bool poisoned = false;                      // a submission of this graph failed half-published, or its final wait failed: leak, do not free
+    double submit_timeout_s = 65.0;             // host-side bound on waiting for ring space (CSIC_DIRECT_SUBMIT_TIMEOUT_MS)
     hsa_signal_t done[DIRECT_SLOTS][MAX_QUEUES] = {};
     bool have_signals = false;
     int64_t next_ticket = 0, waited = 0;        // tickets < waited have completed and been observed
@@ -388,30 +405,41 @@ struct csic_frame_graph {
     uint64_t *passed_word = nullptr;                        // same allocation (+64): DIRECT_SLOTS words, see HandoffArgs::passed --
                                                             // per slot, so that launches of one graph on different streams may finish in any order
     int64_t slot_ticket[DIRECT_SLOTS] = {};                 // ticket of the stream-ordered launch that last used the slot
+    int32_t slot_queues[DIRECT_SLOTS] = {};                 // queues the slot's submission went to
+    bool slot_gated[DIRECT_SLOTS] = {};                     // kernel-gated: queue 0's closing packet does NOT depend on the other queues
     uint64_t timeout_ticks = 0;
 };
 constexpr size_t GATEARG_STRIDE = 512;
 
 static void graph_free(csic_frame_graph *g)
 {
+    // HIP backend: the chains on the pooled streams must have finished before their execs and events go away (the
+    // caller's launch stream is the caller's to synchronise first: csic.h)
+    for (auto s : g->streams) if (s) (void)hipStreamSynchronize(s);        // pooled: not destroyed here
     for (auto ex : g->execs) if (ex) (void)hipGraphExecDestroy(ex);
     for (auto gr : g->graphs) if (gr) (void)hipGraphDestroy(gr);
     for (auto ev : g->joins) if (ev) (void)hipEventDestroy(ev);
     if (g->fork) (void)hipEventDestroy(g->fork);
-    for (auto s : g->streams) if (s) (void)hipStreamSynchronize(s);        // pooled: not destroyed here
-    if (g->d_kernarg) (void)hipFree(g->d_kernarg);
-    if (g->d_gateargs) (void)hipFree(g->d_gateargs);
-    if (g->err_word) (void)hipHostFree(g->err_word);
     if (g->d_tables) (void)hipFree(g->d_tables);
-    if (g->have_signals && !g->stream_ordered)
+    // DIRECT backend.  A poisoned graph (a submission failed half-published, or the final wait did not come back) may
+    // still have packets queued and gate / hand-off waves spinning that refer to its kernargs, signal words and pinned
+    // words: freeing them would be a use-after-free ON THE DEVICE (a memory fault takes every process on the GPU down),
+    // so they are leaked -- a few hundred kilobytes, once, on a path that only a hung GPU reaches.
+    const bool leak = g->poisoned || (g->eng && g->eng->failed);
+    if (!leak) {
+        if (g->d_kernarg) (void)hipFree(g->d_kernarg);
+        if (g->d_gateargs) (void)hipFree(g->d_gateargs);
+        if (g->err_word) (void)hipHostFree(g->err_word);
+        if (g->have_signals && !g->stream_ordered)
+            for (int s = 0; s < DIRECT_SLOTS; ++s)
+                for (int j = 0; j < MAX_QUEUES; ++j)
+                    if (g->done[s][j].handle) (void)hsa_signal_destroy(g->done[s][j]);
         for (int s = 0; s < DIRECT_SLOTS; ++s)
-            for (int j = 0; j < MAX_QUEUES; ++j)
-                if (g->done[s][j].handle) (void)hsa_signal_destroy(g->done[s][j]);
-    for (int s = 0; s < DIRECT_SLOTS; ++s) {
-        for (int j = 0; j < 1 + MAX_QUEUES; ++j)
-            if (g->sigmem[s][j]) (void)hipFree(g->sigmem[s][j]);
-        if (g->consumed[s]) (void)hipEventDestroy(g->consumed[s]);
+            for (int j = 0; j < 1 + MAX_QUEUES; ++j)
+                if (g->sigmem[s][j]) (void)hipFree(g->sigmem[s][j]);
     }
+    for (int s = 0; s < DIRECT_SLOTS; ++s)
+        if (g->consumed[s]) (void)hipEventDestroy(g->consumed[s]);
     if (g->eng) engine_release(g->eng);
     delete g;
 }
@@ -484,6 +512,18 @@ static int build_direct(csic_frame_graph *g, csic_plan *plan, const void *const 
     if (st != CSIC_OK) return st;
     DirectEngine *e = g->eng;
     std::lock_guard<std::mutex> lk(e->mu);
+    if (e->failed) return set_error(CSIC_EHIP, "the direct-dispatch engine of device %d failed earlier: %s", g->device, e->failure.c_str());
+    g->lbranches = g->branches < MAX_STREAM_ORDERED_QUEUES ? g->branches : MAX_STREAM_ORDERED_QUEUES;
+    {
+        // Bounds.  Device side: the gate / hand-off spins give up after CSIC_DIRECT_TIMEOUT_MS (default 30 s).  Host side: a
+        // submission waits for ring space at most CSIC_DIRECT_SUBMIT_TIMEOUT_MS (default: twice the device bound + 5 s, so
+        // that a stalled stream shows up as the device-side timeout it is, not as a ring that does not drain).
+        double ms = 30000.0;
+        if (const char *t = std::getenv("CSIC_DIRECT_TIMEOUT_MS")) { const double v = std::atof(t); if (v >= 1.0) ms = v; }
+        g->timeout_ticks = (uint64_t)(ms * 1.0e5);                               // s_memrealtime counts at 100 MHz
+        g->submit_timeout_s = 2.0e-3 * ms + 5.0;
+        if (const char *t = std::getenv("CSIC_DIRECT_SUBMIT_TIMEOUT_MS")) { const double v = std::atof(t); if (v >= 1.0) g->submit_timeout_s = 1.0e-3 * v; }
+    }
     // resolve every node first (kernarg sizes may differ if some frames fall back to the 4-byte kernels)
     std::vector<LaunchDesc> descs;
     std::vector<KernelInfo> infos;
@@ -522,7 +562,10 @@ static int build_direct(csic_frame_graph *g, csic_plan *plan, const void *const 
         p.grid_size_x = d.grid.x * d.block.x; p.grid_size_y = d.grid.y * d.block.y; p.grid_size_z = d.grid.z * d.block.z;
         p.kernel_object = infos[k].object;
         p.kernarg_address = static_cast<uint8_t *>(g->d_kernarg) + (size_t)k * stride;
-        try { g->packets[k % g->branches].push_back(p); } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
+        try {
+            g->packets[k % g->branches].push_back(p);
+            if (g->lbranches < g->branches) g->lpackets[k % g->lbranches].push_back(p);
+        } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
     }
     // signals: HIP signal memory when the runtime offers it (stream-ordered launches), plain HSA signals otherwise
     int can = 0;
@@ -550,9 +593,6 @@ static int build_direct(csic_frame_graph *g, csic_plan *plan, const void *const 
         const char *mode = std::getenv("CSIC_DIRECT_HANDOFF");
         if (!(mode && std::strcmp(mode, "cp") == 0)) {
             // device-polled hand-off; any failure to set it up leaves the command-processor path in place
-            double ms = 30000.0;
-            if (const char *t = std::getenv("CSIC_DIRECT_TIMEOUT_MS")) { const double v = std::atof(t); if (v >= 1.0) ms = v; }
-            g->timeout_ticks = (uint64_t)(ms * 1.0e5);                           // s_memrealtime counts at 100 MHz
             KernelInfo gi;
             void *ew = nullptr;
             if (engine_kernel(e, reinterpret_cast<const void *>(k_gate_wait), sizeof(GateArgs), &gi) == CSIC_OK &&
@@ -639,6 +679,7 @@ static int wait_slot(csic_frame_graph *g, int64_t ticket)
 
 static int direct_wait(csic_frame_graph *g, int64_t ticket)
 {
+    if (g->poisoned) return set_error(CSIC_EHIP, "direct dispatch: an earlier submission of this graph failed; the graph is unusable");
     if (ticket < 0 || ticket >= g->next_ticket) ticket = g->next_ticket - 1;
     while (g->waited <= ticket) {
         int st = wait_slot(g, g->waited);
@@ -648,19 +689,78 @@ static int direct_wait(csic_frame_graph *g, int64_t ticket)
     return CSIC_OK;
 }
 
+// Waits until `need` more packets fit in q's ring behind the read index.  Every writer of these queues holds e->mu, so the
+// write index cannot move under the caller: once this returns true the reservation that follows cannot overrun the ring.
+// Nothing is reserved while waiting -- a wait that gives up leaves the queue exactly as it found it.
+static bool ring_wait(hsa_queue_t *q, uint64_t need, double timeout_s)
+{
+    const uint64_t w = hsa_queue_load_write_index_relaxed(q);
+    timespec t0{}, now{};
+    for (uint64_t spins = 0; w + need - hsa_queue_load_read_index_scacquire(q) > q->size; ++spins) {
+        if (spins == 0) clock_gettime(CLOCK_MONOTONIC, &t0);
+        if ((spins & 63) != 63) continue;
+        clock_gettime(CLOCK_MONOTONIC, &now);
+        const double el = (double)(now.tv_sec - t0.tv_sec) + 1e-9 * (double)(now.tv_nsec - t0.tv_nsec);
+        if (el > timeout_s) return false;
+        if (el > 2.0e-4) { const timespec nap{0, 20000}; nanosleep(&nap, nullptr); }
+    }
+    return true;
+}
+
+// A submission failed after some of its packets were published: nobody can complete it.  Open its gate (no wave may stay
+// blocked on it), mark graph and engine failed (later submissions on the device get `why` back, nothing is freed under the
+// packets -- see DirectEngine::failed) and report.  Called with e->mu held.
+static int poison(DirectEngine *e, csic_frame_graph *g, int slot, bool gated, int queue)
+{
+    if (gated) {
+        if (g->stream_ordered) __atomic_store_n(g->sigmem[slot][0], (uint64_t)0, __ATOMIC_RELEASE);
+        if (!g->kernel_handoff && g->gate[slot].handle) hsa_signal_store_screlease(g->gate[slot], 0);
+    }
+    g->poisoned = true;
+    e->failed = true;
+    char buf[160];
+    std::snprintf(buf, sizeof buf, "queue %d stopped draining in the middle of a submission (waited %.1f s)", queue, g->submit_timeout_s);
+    e->failure = buf;
+    return set_error(CSIC_EHIP, "direct dispatch: %s; the engine of device %d is disabled", buf, e->device);
+}
+
 // gated = stream-ordered: every queue starts with a gate on the slot's gate word -- a k_gate_wait dispatch (device-polled
 // hand-off) or a barrier-AND packet on the gate signal -- which the launch stream opens once its earlier work is done.
+// A gated submission uses the graph's first `lbranches` queues (lpackets), a host-ordered one all `branches` of them.
 static int direct_submit(csic_frame_graph *g, int64_t *ticket, bool gated = false)
 {
     DirectEngine *e = g->eng;
+    if (g->poisoned) return set_error(CSIC_EHIP, "direct dispatch: an earlier submission of this graph failed; the graph is unusable");
     if (g->next_ticket - g->waited >= DIRECT_SLOTS) {           // recycle the oldest slot: the host waits for it
         int st = direct_wait(g, g->waited);
         if (st != CSIC_OK) return st;
     }
     const int64_t t = g->next_ticket;
     const int slot = (int)(t % DIRECT_SLOTS);
+    const bool narrow = gated && g->lbranches < g->branches;
+    const int nq = narrow ? g->lbranches : g->branches;         // this submission's queues: the engine's first `nq`
+    const std::vector<hsa_kernel_dispatch_packet_t> *pk = narrow ? g->lpackets : g->packets;
+    const bool kgate = gated && g->kernel_handoff;
+    // Queues are filled in lock step, a chunk at a time, so that a graph larger than the rings flows through them.
+    const uint32_t CHUNK = 512;
+    // closing packets: queues 1.. end with one barrier-AND that completes their own signal; queue 0 ends with
+    // barrier-AND packet(s) that additionally DEPEND on those signals (5 dependencies per packet) and complete
+    // done[slot][0] -- the one signal the host waits for (k_handoff polls every queue's done word itself)
+    auto nclose = [&](int j) -> uint32_t { return (j == 0 && nq > 6 && !kgate) ? 2u : 1u; };
+
     std::lock_guard<std::mutex> lk(e->mu);
-    const int nq = g->branches;                                 // this graph's queues: the engine's first `nq`
+    if (e->failed) return set_error(CSIC_EHIP, "the direct-dispatch engine of device %d failed earlier: %s", e->device, e->failure.c_str());
+    // Phase 1 -- nothing published yet: room for the gate, the first chunk and (if that is all) the closing packets on
+    // EVERY queue.  A queue that does not make room in time fails the call cleanly: no reservation, no armed signal.
+    for (int j = 0; j < nq; ++j) {
+        // (a gated submission must fit as a whole: its later chunks would wait behind its own closed gate; launch() has
+        // checked that it can)
+        const size_t n = pk[j].size();
+        const uint64_t need = gated ? 1u + n + nclose(j) : (n < CHUNK ? n : CHUNK) + (n <= CHUNK ? nclose(j) : 0u);
+        if (!ring_wait(e->q[j], need, g->submit_timeout_s))
+            return set_error(CSIC_EHIP, "direct dispatch: queue %d is not draining (no room for %llu packets after %.1f s); nothing was submitted",
+                             j, (unsigned long long)need, g->submit_timeout_s);
+    }
     // Re-arm the slot's signals.  hsa_signal_store_* on an interrupt-capable signal also raises its event -- a KFD ioctl of
     // several microseconds, per signal -- which nobody listens for here (the slot is idle: no waiter, no packet refers to it
     // yet).  With HIP signal memory the value word is ours to write, so a plain store does (measured: 10 us per queue off a
@@ -671,88 +771,81 @@ static int direct_submit(csic_frame_graph *g, int64_t *ticket, bool gated = fals
     } else {
         for (int j = 0; j < nq; ++j) hsa_signal_store_relaxed(g->done[slot][j], 1);
     }
-    const bool kgate = gated && g->kernel_handoff;
-    if (gated) {
-        const uint16_t h_gate = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                                (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE);
-        const uint16_t h_kgate = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE);   // no barrier bit: it only waits
-        for (int j = 0; j < nq; ++j) {
-            hsa_queue_t *q = e->q[j];
-            const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
-            for (uint64_t spins = 0; idx + 1 - hsa_queue_load_read_index_scacquire(q) > q->size; ++spins)
-                if (spins > 2000000000ull) return set_error(CSIC_EHIP, "direct dispatch: queue %d is not draining", j);
-            void *slotp = static_cast<hsa_kernel_dispatch_packet_t *>(q->base_address) + (idx & (q->size - 1));
-            if (kgate) {
-                // one wave that spins on the gate word; the first frame's barrier bit makes the queue wait for it
-                auto *kp = static_cast<hsa_kernel_dispatch_packet_t *>(slotp);
-                std::memset(reinterpret_cast<uint8_t *>(kp) + 4, 0, sizeof *kp - 4);
-                kp->workgroup_size_x = 64; kp->workgroup_size_y = 1; kp->workgroup_size_z = 1;
-                kp->grid_size_x = 64; kp->grid_size_y = 1; kp->grid_size_z = 1;
-                kp->kernel_object = g->gate_kernel.object;
-                kp->kernarg_address = static_cast<uint8_t *>(g->d_gateargs) + (size_t)slot * GATEARG_STRIDE;
-                publish(kp, h_kgate, 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
-            } else {
-                auto *bp = static_cast<hsa_barrier_and_packet_t *>(slotp);
-                std::memset(reinterpret_cast<uint8_t *>(bp) + 4, 0, sizeof *bp - 4);
-                bp->dep_signal[0] = g->gate[slot];
-                publish(bp, h_gate, 0);
-            }
-            // no doorbell of its own: the packets written next ring it past this index
-        }
-    }
     const uint16_t setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
     const uint16_t h_first = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                              (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE);
     const uint16_t h_next = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE);      // no barrier bit, no fences
     const uint16_t h_close = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                              (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
-    // Queues are filled in lock step, a chunk at a time, so that a graph larger than the rings flows through them.
-    const uint32_t CHUNK = 512;
+    const uint16_t h_gate = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                            (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE);
+    const uint16_t h_kgate = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE);     // no barrier bit: it only waits
     size_t pos[MAX_QUEUES] = {};
     bool closed[MAX_QUEUES] = {};
     int open = nq;
+    bool first_round = true;
     while (open > 0) {
         for (int j = 0; j < nq; ++j) {
             if (closed[j]) continue;
             hsa_queue_t *q = e->q[j];
-            const size_t left = g->packets[j].size() - pos[j];
+            const size_t left = pk[j].size() - pos[j];
             const uint32_t nk = (uint32_t)(left < CHUNK ? left : CHUNK);
             const bool last = (left == nk);
-            // closing packets: queues 1.. end with one barrier-AND that completes their own signal; queue 0 ends with
-            // barrier-AND packet(s) that additionally DEPEND on those signals (5 dependencies per packet) and complete
-            // done[slot][0] -- the one signal the host or the launch stream waits for
-            const uint32_t nclose = (j == 0 && nq > 6) ? 2u : 1u;
-            const uint32_t total = nk + (last ? nclose : 0u);
-            const uint64_t idx = hsa_queue_add_write_index_relaxed(q, total);
-            // flow control: the reserved range must fit in the ring behind the read index
-            for (uint64_t spins = 0; idx + total - hsa_queue_load_read_index_scacquire(q) > q->size; ++spins)
-                if (spins > 2000000000ull) return set_error(CSIC_EHIP, "direct dispatch: queue %d is not draining", j);
+            const uint32_t ngate = (first_round && gated) ? 1u : 0u;
+            const uint32_t ncl = last ? nclose(j) : 0u;
+            const uint32_t total = ngate + nk + ncl;
+            // later chunks wait for room again; by now packets of this submission are out, so giving up poisons the engine
+            if (!first_round && !ring_wait(q, total, g->submit_timeout_s)) return poison(e, g, slot, gated, j);
+            const uint64_t idx0 = hsa_queue_add_write_index_relaxed(q, total);
             auto *ring = static_cast<hsa_kernel_dispatch_packet_t *>(q->base_address);
             const uint64_t mask = q->size - 1;
+            uint64_t idx = idx0;
+            if (ngate) {
+                void *slotp = &ring[idx & mask];
+                if (kgate) {
+                    // one wave that spins on the gate word; the first frame's barrier bit makes the queue wait for it
+                    auto *kp = static_cast<hsa_kernel_dispatch_packet_t *>(slotp);
+                    std::memset(reinterpret_cast<uint8_t *>(kp) + 4, 0, sizeof *kp - 4);
+                    kp->workgroup_size_x = 64; kp->workgroup_size_y = 1; kp->workgroup_size_z = 1;
+                    kp->grid_size_x = 64; kp->grid_size_y = 1; kp->grid_size_z = 1;
+                    kp->kernel_object = g->gate_kernel.object;
+                    kp->kernarg_address = static_cast<uint8_t *>(g->d_gateargs) + (size_t)slot * GATEARG_STRIDE;
+                    publish(kp, h_kgate, 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
+                } else {
+                    auto *bp = static_cast<hsa_barrier_and_packet_t *>(slotp);
+                    std::memset(reinterpret_cast<uint8_t *>(bp) + 4, 0, sizeof *bp - 4);
+                    bp->dep_signal[0] = g->gate[slot];
+                    publish(bp, h_gate, 0);
+                }
+                idx += 1;
+            }
             for (uint32_t i = 0; i < nk; ++i) {
                 hsa_kernel_dispatch_packet_t *dst = &ring[(idx + i) & mask];
-                const hsa_kernel_dispatch_packet_t &src = g->packets[j][pos[j] + i];
+                const hsa_kernel_dispatch_packet_t &src = pk[j][pos[j] + i];
                 std::memcpy(reinterpret_cast<uint8_t *>(dst) + 4, reinterpret_cast<const uint8_t *>(&src) + 4, sizeof src - 4);
                 publish(dst, (pos[j] + i == 0) ? h_first : h_next, setup);
             }
             if (last) {
                 int dep = 1;                                            // next other-queue signal queue 0 still has to await
-                for (uint32_t c = 0; c < nclose; ++c) {
+                for (uint32_t c = 0; c < ncl; ++c) {
                     auto *bp = reinterpret_cast<hsa_barrier_and_packet_t *>(&ring[(idx + nk + c) & mask]);
                     std::memset(reinterpret_cast<uint8_t *>(bp) + 4, 0, sizeof *bp - 4);
                     if (j == 0 && !kgate)                               // (k_handoff polls every queue's done word itself)
                         for (int k = 0; k < 5 && dep < nq; ++k) bp->dep_signal[k] = g->done[slot][dep++];
-                    if (c + 1 == nclose) bp->completion_signal = g->done[slot][j];
+                    if (c + 1 == ncl) bp->completion_signal = g->done[slot][j];
                     publish(bp, h_close, 0);
                 }
                 closed[j] = true;
                 open -= 1;
             }
             pos[j] += nk;
-            hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx + total - 1));
+            hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(idx0 + total - 1));
         }
+        first_round = false;
     }
     g->next_ticket = t + 1;
+    g->slot_queues[slot] = nq;
+    g->slot_gated[slot] = kgate;
     if (ticket) *ticket = t;
     return CSIC_OK;
 }
@@ -766,6 +859,10 @@ int csic_frame_graph_create_ex(csic_plan *plan, const void *const *d_in, void *c
     *out = nullptr;
     if (!plan || !d_in || !d_out) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
     if (nframes < 1 || nframes > 65536) return set_error(CSIC_EINVAL_SIZE, "nframes must be in 1..65536. Got %d", nframes);
+    // AUTO: every frame of a graph shares one plan, so ONE launch over a pointer table always applies and is the fastest
+    // stream-ordered way through them at every frame size (profiles/r02_small_launch.md); the per-frame-launch backends are
+    // for callers that ask for per-frame launches by name.
+    if (backend == CSIC_FRAME_GRAPH_AUTO) backend = CSIC_FRAME_GRAPH_FUSED;
     if (backend != CSIC_FRAME_GRAPH_HIP && backend != CSIC_FRAME_GRAPH_DIRECT && backend != CSIC_FRAME_GRAPH_FUSED)
         return set_error(CSIC_EINVAL_SIZE, "unknown frame-graph backend %d", backend);
     if (backend == CSIC_FRAME_GRAPH_FUSED) branches = 1;          // one launch: nothing to overlap with
@@ -805,7 +902,7 @@ int csic_frame_graph_create_ex(csic_plan *plan, const void *const *d_in, void *c
 int csic_frame_graph_create(csic_plan *plan, const void *const *d_in, void *const *d_out, int32_t nframes,
                             int32_t branches, csic_frame_graph **out)
 {
-    return csic_frame_graph_create_ex(plan, d_in, d_out, nframes, branches, CSIC_FRAME_GRAPH_HIP, out);
+    return csic_frame_graph_create_ex(plan, d_in, d_out, nframes, branches, CSIC_FRAME_GRAPH_AUTO, out);
 }
 
 int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
@@ -823,11 +920,20 @@ int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
     }
     if (g->backend == CSIC_FRAME_GRAPH_DIRECT) {
         int64_t t = 0;
+        // Not capturable: the packets go to the library's queues NOW, only the hand-off would be recorded -- a replay of the
+        // captured graph would run a hand-off without a submission behind it (stale outputs, a slot that is never released),
+        // and the host-ordered fallback synchronises the stream, which invalidates a capture.  HIP and FUSED graphs capture.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        if (cap != hipStreamCaptureStatusNone)
+            return set_error(CSIC_ECAPTURE, "a CSIC_FRAME_GRAPH_DIRECT launch cannot be captured into a hipGraph (the stream is "
+                                            "capturing); use the CSIC_FRAME_GRAPH_HIP or CSIC_FRAME_GRAPH_FUSED backend under capture");
         // A gated submission sits in the rings until the stream opens the gate -- which it is only asked to do after the
         // submission has been written.  One that does not fit in a ring (gate + packets + closing packets) can therefore
         // not be armed ahead of time; it takes the host-ordered path.
+        const std::vector<hsa_kernel_dispatch_packet_t> *pk = g->lbranches < g->branches ? g->lpackets : g->packets;
         size_t longest = 0;
-        for (int j = 0; j < g->branches; ++j) longest = g->packets[j].size() > longest ? g->packets[j].size() : longest;
+        for (int j = 0; j < g->lbranches; ++j) longest = pk[j].size() > longest ? pk[j].size() : longest;
         const bool fits = longest + 3 <= QUEUE_PACKETS;
         if (!g->stream_ordered || !fits) {
             // no shared signals on this runtime (or a graph larger than the rings): order by the host
@@ -844,20 +950,31 @@ int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
         int st = direct_submit(g, &t, true);
         if (st != CSIC_OK) return st;
         const int slot = (int)(t % DIRECT_SLOTS);
+        const int nq = g->slot_queues[slot];
         if (g->kernel_handoff) {
             HandoffArgs ha{};
             ha.gate = g->sigmem[slot][0];
-            for (int j = 0; j < g->branches; ++j) ha.done[j] = g->sigmem[slot][1 + j];
+            for (int j = 0; j < nq; ++j) ha.done[j] = g->sigmem[slot][1 + j];
             ha.err = g->err_word;
             ha.passed = &g->passed_word[slot];
             ha.seq = (uint64_t)t + 1;
             ha.timeout_ticks = g->timeout_ticks;
-            ha.nq = g->branches;
+            ha.nq = nq;
             void *params[1] = {&ha};
             hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(k_handoff), dim3(1), dim3(64), params, 0, stream);
             if (e != hipSuccess) {
-                __atomic_store_n(g->sigmem[slot][0], (uint64_t)0, __ATOMIC_RELEASE);     // never leave the queues blocked
-                return set_error(CSIC_EHIP, "launching the hand-off kernel failed: %s", hipGetErrorString(e));
+                // The queues are armed behind the gate and no hand-off will ever open it: open it from the host (the frames
+                // then run unordered with the stream, which the error return tells the caller) and wait here for EVERY
+                // queue's closing packet -- in this mode queue 0's does not depend on the others -- so that the ticket
+                // direct_submit issued is complete before anybody recycles its slot or frees the graph.
+                (void)hipGetLastError();
+                __atomic_store_n(g->sigmem[slot][0], (uint64_t)0, __ATOMIC_RELEASE);
+                bool drained = true;
+                for (int j = 0; j < nq; ++j)
+                    if (hsa_signal_wait_scacquire(g->done[slot][j], HSA_SIGNAL_CONDITION_LT, 1, WAIT_TICKS, HSA_WAIT_STATE_BLOCKED) >= 1) drained = false;
+                if (!drained) g->poisoned = true;
+                return set_error(CSIC_EHIP, "launching the hand-off kernel failed: %s%s", hipGetErrorString(e),
+                                 drained ? " (the frames ran unordered with the stream)" : "; the queues did not drain either");
             }
             g->slot_ticket[slot] = t;
             g->slot_on_stream[slot] = true;
@@ -867,7 +984,9 @@ int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
         hipError_t e = hipStreamWriteValue64(stream, g->sigmem[slot][0], 0, 0);
         if (e != hipSuccess) {
             // the queues are armed behind the gate: never leave them blocked -- open it from the host (the work then
-            // runs unordered with the stream, which the error return tells the caller) and fall back to a host wait
+            // runs unordered with the stream, which the error return tells the caller); the ticket completes through
+            // queue 0's closing packet as a host-ordered submission's would
+            (void)hipGetLastError();
             hsa_signal_store_screlease(g->gate[slot], 0);
             return set_error(CSIC_EHIP, "hipStreamWriteValue64 failed: %s", hipGetErrorString(e));
         }
@@ -922,6 +1041,13 @@ int csic_frame_graph_count(const csic_frame_graph *g, int32_t *nframes, int32_t 
     return CSIC_OK;
 }
 
+int csic_frame_graph_launch_branches(const csic_frame_graph *g)
+{
+    if (!g) return set_error(CSIC_EINVAL_NULL, "graph is NULL");
+    if (g->backend == CSIC_FRAME_GRAPH_FUSED) return 1;
+    return g->backend == CSIC_FRAME_GRAPH_DIRECT ? g->lbranches : g->branches;
+}
+
 int csic_frame_graph_backend(const csic_frame_graph *g)
 {
     if (!g) return set_error(CSIC_EINVAL_NULL, "graph is NULL");
@@ -938,7 +1064,9 @@ int csic_frame_graph_destroy(csic_frame_graph *g)
 {
     if (!g) return CSIC_OK;
     DeviceGuard guard(g->device);
-    if (g->backend == CSIC_FRAME_GRAPH_DIRECT && g->eng && g->next_ticket > g->waited) (void)direct_wait(g, -1);
+    if (g->backend == CSIC_FRAME_GRAPH_DIRECT && g->eng && g->next_ticket > g->waited && !g->poisoned &&
+        direct_wait(g, -1) != CSIC_OK)
+        g->poisoned = true;                     // something of this graph may still be queued or spinning: leak its device memory
     graph_free(g);
     return CSIC_OK;
 }

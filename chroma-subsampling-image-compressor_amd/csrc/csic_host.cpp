@@ -263,6 +263,7 @@ const char *csic_strerror(int status)
     case CSIC_ENODEVICE: return "no HIP device";
     case CSIC_EHIP: return "HIP runtime error";
     case CSIC_ENOMEM: return "out of memory";
+    case CSIC_ECAPTURE: return "the stream is capturing and this operation cannot be captured";
     case CSIC_EIO: return "file I/O error";
     case CSIC_EFORMAT: return "bad or unsupported PNG";
     default: return "unknown status";

@@ -60,6 +60,7 @@ typedef enum csic_status {
     CSIC_ENODEVICE              = -20, /* no HIP device / bad device ordinal                           */
     CSIC_EHIP                   = -21, /* a HIP runtime call failed (message has the HIP error string) */
     CSIC_ENOMEM                 = -22,
+    CSIC_ECAPTURE               = -23, /* the HIP stream is capturing and this operation cannot be captured */
     CSIC_EIO                    = -30, /* file cannot be opened / read / written                       */
     CSIC_EFORMAT                = -31  /* not a PNG, corrupt, or an unsupported PNG feature            */
 } csic_status;
@@ -268,11 +269,29 @@ int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *
  *                            submission.  Up to 16 submissions/launches may be outstanding per graph (a 17th waits
  *                            for the oldest); host-ordered submissions are not ordered among themselves.
  *                            Queue count: the device runs 4 queues at once.  Host-ordered submissions are fastest
- *                            on 4 (cfg 5 frame 1.71 us, 3 queues 1.78 us); a stream-ordered launch also keeps the
- *                            launch stream's own queue busy, and with 4 + 1 active queues the hardware scheduler
- *                            time-slices them (64 frames: 250 us instead of 126 us) -- hence the default of 3.  A
- *                            stream-ordered launch costs about 8 us of hand-off on top of the host-ordered time
- *                            (17-40 us in the command-processor form): record several frames per graph.
+ *                            on 4 (cfg 5 frame 1.71 us, 3 queues 1.78 us).  A stream-ordered launch also keeps the
+ *                            launch stream's own queue busy (its hand-off kernel runs as long as the frames do), and with
+ *                            4 + 1 active queues the hardware scheduler time-slices them (64 frames: 250 us instead of
+ *                            126 us) -- so csic_frame_graph_launch NEVER uses more than 3 queues: a graph created with
+ *                            more keeps a second dealing of its frames over 3 queues for launches and uses all of them
+ *                            for csic_frame_graph_submit.  A stream-ordered launch costs about 8 us of hand-off on top
+ *                            of the host-ordered time (17-40 us in the command-processor form): record several frames
+ *                            per graph.
+ *                            Limits a caller must know:
+ *                            - NOT capturable.  csic_frame_graph_launch on a capturing stream returns CSIC_ECAPTURE (the
+ *                              packets would go out at capture time and a replay would find nothing behind its hand-off).
+ *                            - The gate waves are dispatched when the host calls launch, not when the stream gets there:
+ *                              stream work in front of a launch that runs LONGER than CSIC_DIRECT_TIMEOUT_MS makes the
+ *                              gate give up -- the frames then run on inputs that may not be ready, the graph's error
+ *                              word is set, and the next launch / wait / destroy of that graph reports CSIC_EHIP.  Raise
+ *                              the timeout for such hosts; it bounds how long a wave may spin, nothing else.
+ *                            - Waiting for ring space is bounded too (CSIC_DIRECT_SUBMIT_TIMEOUT_MS, default twice the
+ *                              device bound + 5 s).  Room is checked on every queue BEFORE anything is written, so a
+ *                              submission that cannot start fails cleanly (nothing queued, the engine stays usable).
+ *                              Only a graph larger than the rings (> 4096 packets per queue, host-ordered) can fail between
+ *                              two chunks; that marks the device's engine failed: every later DIRECT call on the device
+ *                              returns CSIC_EHIP with the first failure's message, and what the stuck packets refer to
+ *                              is leaked instead of freed.
  *
  *   CSIC_FRAME_GRAPH_FUSED   not per-frame launches at all: ONE kernel launch covers every frame (frame index on the
  *                            grid's z axis, the frame bases read from a device-resident pointer table the graph owns), so
@@ -280,15 +299,21 @@ int  csic_checksum_device(const void *d_src, int64_t npix, uint64_t *sum, void *
  *                            csic_frame_graph_launch is an ordinary asynchronous launch on `hip_stream`: fully ordered,
  *                            hipGraph-capturable, no internal streams or queues (`branches` is ignored).
  *
- * A graph, like a plan, is not thread-safe (one thread at a time per graph; different graphs may be used from different
- * threads, the library serialises their access to its queues).
+ * A graph, like a plan, is not thread-safe (one thread at a time per graph, including its ticket bookkeeping; different
+ * graphs may be used from different threads, the library serialises their access to its queues).
+ * csic_frame_graph_destroy waits for the graph's DIRECT submissions and for the HIP backend's internal streams; work that
+ * csic_frame_graph_launch put on the CALLER's stream (chain 0 of the HIP backend, the fused launch) is the caller's to
+ * synchronise before destroying the graph, as with any resource a stream still uses.
  * branches <= 0 selects the backend's default for the frame size (more overlap for smaller frames; measured table
  * in profiles/r02_small_launch.md).  The pointer arrays are read at creation only; the buffers they
  * name must stay valid for as long as the graph is launched.  csic_frame_graph_create == _create_ex with
- * CSIC_FRAME_GRAPH_HIP. */
+ * CSIC_FRAME_GRAPH_AUTO, which today always resolves to FUSED: the plain entry point gives the fastest stream-ordered
+ * path (cfg 5: 76 % of the HBM roofline against 42 % for hipGraph chains); per-frame launches are there for callers who
+ * name them. */
 #define CSIC_FRAME_GRAPH_HIP    0
 #define CSIC_FRAME_GRAPH_DIRECT 1
 #define CSIC_FRAME_GRAPH_FUSED  2
+#define CSIC_FRAME_GRAPH_AUTO   3   /* the library's choice: FUSED (all frames of a graph share one plan, so it always applies) */
 #define CSIC_FRAME_GRAPH_DEFAULT_BRANCHES 4   /* HIP backend, small frames (2 chains when a frame is >= 5 us of HBM time)          */
 #define CSIC_FRAME_GRAPH_DEFAULT_QUEUES   3   /* DIRECT backend, small frames (2 queues from 2.5 us, 1 queue from 10 us per frame); see below */
 typedef struct csic_frame_graph csic_frame_graph;
@@ -300,7 +325,8 @@ int  csic_frame_graph_launch(csic_frame_graph *graph, void *hip_stream);
 int  csic_frame_graph_submit(csic_frame_graph *graph, int64_t *ticket);            /* DIRECT only */
 int  csic_frame_graph_wait(csic_frame_graph *graph, int64_t ticket);               /* DIRECT only; ticket < 0 = all */
 int  csic_frame_graph_count(const csic_frame_graph *graph, int32_t *nframes, int32_t *branches);
-int  csic_frame_graph_backend(const csic_frame_graph *graph);                      /* CSIC_FRAME_GRAPH_* or < 0 */
+int  csic_frame_graph_backend(const csic_frame_graph *graph);                      /* the RESOLVED backend (never AUTO), or < 0 */
+int  csic_frame_graph_launch_branches(const csic_frame_graph *graph);              /* chains / queues csic_frame_graph_launch uses: DIRECT min(branches, 3), FUSED 1 */
 int  csic_frame_graph_stream_ordered(const csic_frame_graph *graph);               /* 1: launch() is asynchronous and ordered with its stream */
 int  csic_frame_graph_destroy(csic_frame_graph *graph);
 

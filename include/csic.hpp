@@ -156,12 +156,13 @@ private:
 // so that small launches overlap.  HIP = hipGraph chains ordered with the caller's stream; DIRECT = AQL packets without
 // barrier bits on the library's own queues -- launch(stream) orders them with a HIP stream on the device, submit()/wait()
 // by the host.  The reference processes one image at a time (ImageCompressorTopApp.scala:53-68).
-enum class FrameGraphBackend : int32_t { HIP = CSIC_FRAME_GRAPH_HIP, DIRECT = CSIC_FRAME_GRAPH_DIRECT, FUSED = CSIC_FRAME_GRAPH_FUSED };
+enum class FrameGraphBackend : int32_t { HIP = CSIC_FRAME_GRAPH_HIP, DIRECT = CSIC_FRAME_GRAPH_DIRECT, FUSED = CSIC_FRAME_GRAPH_FUSED,
+                                         AUTO = CSIC_FRAME_GRAPH_AUTO };
 
 class FrameGraph {
 public:
     FrameGraph(csic_plan *plan, const std::vector<const void *> &d_in, const std::vector<void *> &d_out,
-               FrameGraphBackend backend = FrameGraphBackend::HIP, int branches = 0)
+               FrameGraphBackend backend = FrameGraphBackend::AUTO, int branches = 0)
     {
         if (d_in.size() != d_out.size() || d_in.empty())
             throw IllegalArgumentException(CSIC_EINVAL_SIZE, "need as many output as input frames (> 0)");
@@ -175,6 +176,8 @@ public:
     void wait(int64_t ticket = -1) { check(csic_frame_graph_wait(g_, ticket)); }
     bool streamOrdered() const { return csic_frame_graph_stream_ordered(g_) == 1; }
     int branches() const { int32_t n = 0, b = 0; csic_frame_graph_count(g_, &n, &b); return b; }
+    int launchBranches() const { return csic_frame_graph_launch_branches(g_); }
+    FrameGraphBackend backend() const { return (FrameGraphBackend)csic_frame_graph_backend(g_); }   // the resolved one, never AUTO
 
 private:
     csic_frame_graph *g_ = nullptr;

@@ -159,3 +159,20 @@ def test_committed_traffic_matches_the_checked_out_sources():
     have = kernel_source_sha256(ROOT)
     ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     assert ent["cfg4"]["source_sha256"] == have, "re-run tools/r02_artifacts.sh profile + tools/collect_artifacts.py"
+
+
+def test_every_native_source_of_the_package_is_inside_the_source_hash():
+    """tools/srchash.py hashes csrc/ and include/csic.h.  A kernel header or source anywhere else in the package would be
+    outside the hash that guards `roofline.traffic` (and could shadow the csrc/ copy with another KArgs layout): there must
+    be none.  The JNI glue under jvm/ is host-only C over the C ABI and is exempt."""
+    pkg = os.path.join(ROOT, "chroma-subsampling-image-compressor_amd")
+    stray = []
+    for base, dirs, files in os.walk(pkg):
+        dirs[:] = [d for d in dirs if d != "__pycache__"]
+        rel = os.path.relpath(base, pkg)
+        if rel == "csrc" or rel.startswith("jvm"):
+            continue
+        stray += [os.path.join(rel, f) for f in files if f.endswith((".h", ".hpp", ".hip", ".cpp", ".c", ".cu"))]
+    assert not stray, f"native sources outside csrc/ (not covered by tools/srchash.py): {stray}"
+    inc = [f for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h")]
+    assert inc == ["csic.h"], f"include/*.h must be exactly what srchash hashes: {inc}"

@@ -456,3 +456,191 @@ def test_one_direct_graph_launched_on_two_streams(csic, oracle, monkeypatch):
         for k in range(n):
             want = oracle.process(_oparams(oracle, W, H, 2, 0, (8, 8, 8), 2), host[k], form="closed")
             assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(want.shape), want), k
+
+
+# ---- round 3: defaults, limits and error exits of the launch engine ------------------------------------------------
+def test_auto_backend_is_the_default_and_resolves_to_fused(csic, oracle):
+    """csic_frame_graph_create (no backend named) == CSIC_FRAME_GRAPH_AUTO == the fused launch: the plain entry point must
+    give the fast stream-ordered path, not hipGraph chains."""
+    import torch
+    N = csic._native
+    W, H, n = 320, 48, 9
+    cp = csic.make_c_params(W, H, 2, 0, 3, 3, 2, 4, CSQ)
+    host = [oracle.synth_frame(W * H, 40 + k) for k in range(n)]
+    with csic.Plan(cp, 0) as pl:
+        d_ins = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
+        d_outs = [torch.zeros(pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+        pin = (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) for t in d_ins])
+        pout = (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) for t in d_outs])
+        h = C.c_void_p()
+        N.check(N.lib().csic_frame_graph_create(pl._h, pin, pout, n, 0, C.byref(h)))
+        try:
+            assert N.lib().csic_frame_graph_backend(h) == N.FRAME_GRAPH_FUSED
+            assert N.lib().csic_frame_graph_launch_branches(h) == 1
+            N.check(N.lib().csic_frame_graph_launch(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+        finally:
+            N.lib().csic_frame_graph_destroy(h)
+        for k in range(n):
+            want = oracle.process(_oparams(oracle, W, H, 2, 0, (3, 3, 2), 4), host[k], form="closed")
+            assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(want.shape), want), k
+        with csic.FrameGraph(pl, d_ins, d_outs) as g:                   # the Python mirror's default
+            assert g.requested_backend == "auto" and g.backend == "fused" and g.launch_branches == 1
+
+
+@pytest.mark.parametrize("queues", [4, 8])
+def test_stream_ordered_direct_launch_never_uses_more_than_three_queues(csic, oracle, queues):
+    """A DIRECT graph created with 4 or 8 queues submits on all of them but LAUNCHES on 3: a fourth queue beside the launch
+    stream's own gets time-sliced (the 31 % cliff of VERDICT r02 weak item 3).  Both dealings of the frames are checked."""
+    import torch
+    W, H, n = 256, 40, 23
+    cp = csic.make_c_params(W, H, 2, 0, 5, 5, 4, 2, CSQ)
+    host = [oracle.synth_frame(W * H, 900 + k) for k in range(n)]
+    wants = [oracle.process(_oparams(oracle, W, H, 2, 0, (5, 5, 4), 2), h, form="closed") for h in host]
+    with csic.Plan(cp, 0) as pl:
+        d_ins = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
+        d_outs = [torch.zeros(pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+        torch.cuda.synchronize()
+        with csic.FrameGraph(pl, d_ins, d_outs, branches=queues, backend="direct") as g:
+            assert g.branches == queues
+            assert g.launch_branches == 3
+            for how in ("launch", "submit", "launch", "launch", "submit"):
+                for t in d_outs:
+                    t.zero_()
+                torch.cuda.synchronize()
+                if how == "launch":
+                    g.launch()
+                    torch.cuda.synchronize()
+                else:
+                    g.wait(g.submit())
+                for k in range(n):
+                    assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(wants[k].shape), wants[k]), (how, k)
+
+
+def test_direct_launch_refuses_a_capturing_stream(csic, oracle):
+    """A DIRECT launch is not capturable (its packets would go out at capture time): CSIC_ECAPTURE, the capture itself stays
+    valid, and the FUSED graph of the same frames captures and replays."""
+    import torch
+    W, H, n = 128, 32, 4
+    cp = csic.make_c_params(W, H, 2, 0, 8, 8, 8, 2, CSQ)
+    host = [oracle.synth_frame(W * H, 610 + k) for k in range(n)]
+    with csic.Plan(cp, 0) as pl:
+        d_ins = [torch.from_numpy(h.view(np.int32)).cuda() for h in host]
+        d_outs = [torch.zeros(pl.out_width * pl.out_height, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with csic.FrameGraph(pl, d_ins, d_outs, backend="direct") as gd, csic.FrameGraph(pl, d_ins, d_outs, backend="fused") as gf:
+            with torch.cuda.stream(side):
+                gf.launch(side)
+            side.synchronize()
+            for t in d_outs:
+                t.zero_()
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg, stream=side):
+                with pytest.raises(csic.CsicRuntimeError, match="cannot be captured") as ei:
+                    gd.launch(side)
+                assert ei.value.status == csic._native.ECAPTURE
+                gf.launch(side)                                          # the capture is still valid
+            torch.cuda.synchronize()
+            assert all(int(t.abs().sum()) == 0 for t in d_outs)          # nothing ran at capture time
+            cg.replay()
+            torch.cuda.synchronize()
+            for k in range(n):
+                want = oracle.process(_oparams(oracle, W, H, 2, 0, (8, 8, 8), 2), host[k], form="closed")
+                assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(want.shape), want), k
+            gd.launch()                                                  # and the direct graph is still usable outside capture
+            torch.cuda.synchronize()
+
+
+def _tiny_graph_inputs(csic, oracle, n, seed):
+    import torch
+    W, H = 16, 8
+    cp = csic.make_c_params(W, H, 2, 0, 8, 8, 8, 2, CSQ)
+    host = oracle.synth_frame(n * W * H, seed)
+    pl = csic.Plan(cp, 0)
+    opx = pl.out_width * pl.out_height
+    d_in = torch.from_numpy(host.view(np.int32)).cuda()
+    d_out = torch.zeros(n * opx, dtype=torch.int32, device="cuda:0")
+    ref = torch.zeros_like(d_out)
+    pl.process_device(d_in, ref, nframes=n)
+    torch.cuda.synchronize()
+    ins = [d_in[k * W * H:(k + 1) * W * H] for k in range(n)]
+    outs = [d_out[k * opx:(k + 1) * opx] for k in range(n)]
+    return pl, ins, outs, d_out, ref
+
+
+def test_a_full_ring_fails_the_submission_cleanly_and_the_engine_stays_usable(csic, oracle, monkeypatch):
+    """ADVICE r02 (csic_graph.hip:728): room in the rings is awaited BEFORE anything is reserved.  Launch 1 (3000 frames on one
+    queue) sits behind its gate because the launch stream is stalled; launch 2 does not fit behind it and gives up after
+    CSIC_DIRECT_SUBMIT_TIMEOUT_MS -- with nothing queued, no armed signal and no hole in the ring: a second graph on the same
+    engine goes through, and the first graph launches again once the stream has moved on."""
+    import torch
+    monkeypatch.setenv("CSIC_DIRECT_HANDOFF", "kernel")
+    monkeypatch.setenv("CSIC_DIRECT_TIMEOUT_MS", "8000")
+    monkeypatch.setenv("CSIC_DIRECT_SUBMIT_TIMEOUT_MS", "100")
+    pl, ins, outs, d_out, ref = _tiny_graph_inputs(csic, oracle, 3000, 71)
+    pl2, ins2, outs2, d_out2, ref2 = _tiny_graph_inputs(csic, oracle, 4, 72)
+    try:
+        with csic.FrameGraph(pl, ins, outs, branches=1, backend="direct") as g, \
+                csic.FrameGraph(pl2, ins2, outs2, branches=1, backend="direct") as g2:
+            if not g.stream_ordered:
+                pytest.skip("this runtime offers no HIP signal memory")
+            torch.cuda._sleep(int(2.4e9))                                # ~1 s of stall on the launch stream
+            g.launch()                                                   # 3002 of the 4096 ring slots, gated
+            with pytest.raises(csic.CsicRuntimeError, match="not draining.*nothing was submitted"):
+                g.launch()
+            g2.wait(g2.submit())                                         # queues up behind launch 1, finishes when the stall ends
+            assert torch.equal(d_out2, ref2)
+            torch.cuda.synchronize()
+            assert torch.equal(d_out, ref)
+            d_out.zero_()
+            g.launch()                                                   # the graph and the engine are intact
+            torch.cuda.synchronize()
+            assert torch.equal(d_out, ref)
+    finally:
+        pl.close()
+        pl2.close()
+
+
+def test_a_submission_that_stalls_between_chunks_disables_the_engine_instead_of_wedging_it(csic, oracle, monkeypatch):
+    """The one case that cannot fail cleanly: a host-ordered graph larger than the ring whose later chunk finds no room in
+    time.  Its published packets cannot be recalled, so the engine is marked failed: the call reports it, every later DIRECT
+    call on the device reports the same failure instead of queueing behind the hole, nothing hangs, and nothing the stuck
+    packets refer to is freed.  When the last graph is gone a fresh engine (new queues) serves the next graph."""
+    import torch
+    monkeypatch.setenv("CSIC_DIRECT_HANDOFF", "kernel")
+    monkeypatch.setenv("CSIC_DIRECT_TIMEOUT_MS", "8000")
+    monkeypatch.setenv("CSIC_DIRECT_SUBMIT_TIMEOUT_MS", "100")
+    pl, ins, outs, d_out, ref = _tiny_graph_inputs(csic, oracle, 3000, 81)
+    plb, insb, outsb, d_outb, refb = _tiny_graph_inputs(csic, oracle, 5000, 82)
+    pl2, ins2, outs2, d_out2, ref2 = _tiny_graph_inputs(csic, oracle, 4, 83)
+    try:
+        g = csic.FrameGraph(pl, ins, outs, branches=1, backend="direct")
+        gb = csic.FrameGraph(plb, insb, outsb, branches=1, backend="direct")
+        g2 = csic.FrameGraph(pl2, ins2, outs2, branches=1, backend="direct")
+        try:
+            if not g.stream_ordered:
+                pytest.skip("this runtime offers no HIP signal memory")
+            torch.cuda._sleep(int(2.4e9))                                # ~1 s of stall on the launch stream
+            g.launch()                                                   # fills 3002 of 4096 slots behind its gate
+            with pytest.raises(csic.CsicRuntimeError, match="stopped draining in the middle"):
+                gb.submit()                                              # chunks 1 and 2 fit, chunk 3 does not
+            with pytest.raises(csic.CsicRuntimeError, match="failed earlier"):
+                g2.submit()
+            with pytest.raises(csic.CsicRuntimeError, match="failed earlier"):
+                csic.FrameGraph(pl2, ins2, outs2, branches=1, backend="direct")
+            torch.cuda.synchronize()                                     # the stall ends, launch 1 drains ...
+            import time
+            time.sleep(0.1)                                              # ... and so do the 1024 orphaned packets behind it
+            assert torch.equal(d_out, ref)
+        finally:
+            g2.close()
+            gb.close()
+            g.close()
+        with csic.FrameGraph(pl2, ins2, outs2, branches=1, backend="direct") as g3:     # a fresh engine
+            g3.wait(g3.submit())
+            assert torch.equal(d_out2, ref2)
+    finally:
+        pl.close()
+        plb.close()
+        pl2.close()
