@@ -98,6 +98,20 @@ class StripedImageCompressorTop:
             sp = make_c_params(width, self._proc_rows, *self._gargs, rounding=rounding, out_format=out_format)
             self._plan = plan_factory(sp, self.device)
 
+    def alloc_local(self, device=None):
+        """A stripe buffer with room for the halo IN FRONT of this rank's rows: returns the (nrows, W) int32 view the caller
+        fills with its input rows [row0, row0 + nrows).  When process_local() is handed exactly this view, the neighbour's
+        rows are received straight into the space in front of it and the kernel runs on the buffer in place -- no
+        re-assembly copy of the stripe (at 8192 x 1024 rows that copy is 30 us; the exchange itself moves one row)."""
+        import torch
+        st = self.stripe
+        W = self.global_params.width
+        dev = torch.device("cuda", self.device) if device is None else torch.device(device)
+        halo = max(st.halo_above, 0)
+        self._ext = torch.empty((halo + st.nrows, W), dtype=torch.int32, device=dev)
+        self._local_view = self._ext[halo:]
+        return self._local_view
+
     def _exchange_halo(self, local_rows):
         """One neighbour exchange: my trailing `tail_below` rows go to rank+1, `halo_above` rows arrive from
         rank-1 (isend/irecv pairs).  With backend "nccl" (RCCL) CUDA rows travel GPU to GPU over xGMI; gloo has
@@ -111,6 +125,8 @@ class StripedImageCompressorTop:
         is_np = not hasattr(local_rows, "is_cuda")
         t = torch.from_numpy(np.ascontiguousarray(local_rows).view(np.int32).reshape(-1, W)) if is_np \
             else local_rows.reshape(-1, W)
+        view = getattr(self, "_local_view", None)
+        in_place = (not is_np) and view is not None and t.data_ptr() == view.data_ptr() and t.shape == view.shape
         stage = t.is_cuda and dist.get_backend(self.group) != "nccl"
         wire = torch.device("cpu") if stage else t.device
         ops, halo = [], None
@@ -118,11 +134,16 @@ class StripedImageCompressorTop:
             tail = t[st.nrows - st.tail_below:].contiguous().to(wire)
             ops.append(dist.P2POp(dist.isend, tail, self._global_rank(self.rank + 1), self.group))
         if st.halo_above > 0:
-            halo = torch.empty((st.halo_above, W), dtype=t.dtype, device=wire)
+            halo = self._ext[: st.halo_above] if (in_place and not stage) else \
+                torch.empty((st.halo_above, W), dtype=t.dtype, device=wire)
             ops.append(dist.P2POp(dist.irecv, halo, self._global_rank(self.rank - 1), self.group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        if in_place:                                               # alloc_local(): halo rows land in front of the caller's rows
+            if halo is not None and stage:
+                self._ext[: st.halo_above].copy_(halo)
+            return self._ext[: st.halo_above + st.nrows - st.tail_below]
         body = t[: st.nrows - st.tail_below]
         ext = body if halo is None else torch.cat([halo.to(t.device), body], 0)
         return ext.numpy().view(np.uint32) if is_np else ext.contiguous()

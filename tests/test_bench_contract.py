@@ -158,7 +158,7 @@ def test_committed_traffic_matches_the_checked_out_sources():
     from srchash import kernel_source_sha256
     have = kernel_source_sha256(ROOT)
     ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    assert ent["cfg4"]["source_sha256"] == have, "re-run tools/r02_artifacts.sh profile + tools/collect_artifacts.py"
+    assert ent["cfg4"]["source_sha256"] == have, "re-run tools/artifacts.sh profile + tools/collect_artifacts.py"
 
 
 def test_every_native_source_of_the_package_is_inside_the_source_hash():

@@ -32,13 +32,15 @@ class _OraclePlan:
                                   rounding=c_params.rounding, out_format=c_params.out_format)
 
     def process(self, frame):
+        if hasattr(frame, "numpy"):                                 # a torch CPU tensor (alloc_local path)
+            frame = frame.contiguous().numpy().view(np.uint32)
         return self.orc.process(self.p, frame)
 
     def close(self):
         pass
 
 
-def _worker(rank, world, port, case, result_path, splits=None):
+def _worker(rank, world, port, case, result_path, splits=None, in_place=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -50,7 +52,15 @@ def _worker(rank, world, port, case, result_path, splits=None):
         frame = orc.synth_frame(W * H, 4321).reshape(H, W)          # every rank can regenerate the frame
         top = csic.StripedImageCompressorTop(W, H, a, b, *bits, f, *op, plan_factory=_OraclePlan, row_splits=splits)
         s = top.stripe
-        local = top.process_local(frame[s.row0:s.row0 + s.nrows]) if s.nrows else None
+        if in_place and s.nrows:
+            # the caller's rows live behind room for the halo: the neighbour's rows are received in place, nothing is re-assembled
+            import torch
+            view = top.alloc_local("cpu")
+            view.copy_(torch.from_numpy(frame[s.row0:s.row0 + s.nrows].view(np.int32).copy()))
+            local = top.process_local(view)
+            assert top._ext.data_ptr() == view.data_ptr() - 4 * s.halo_above * W
+        else:
+            local = top.process_local(frame[s.row0:s.row0 + s.nrows]) if s.nrows else None
         if local is not None:
             assert local.shape == (s.out_nrows, top.out_width)
         full = top.gather(local, dst=0)
@@ -99,6 +109,16 @@ def test_unaligned_stripes_with_halo_exchange_gloo(tmp_path, world, case, s2, s3
     result = tmp_path / "result.txt"
     splits = s2 if world == 2 else s3
     mp.spawn(_worker, args=(world, _free_port(), case, str(result), splits), nprocs=world, join=True)
+    assert result.read_text() == "ok"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case,s2,s3", HALO_CASES[1:4])
+def test_halo_received_in_place_in_front_of_the_callers_rows(tmp_path, world, case, s2, s3):
+    """alloc_local(): the same exchange without the re-assembly copy of the stripe."""
+    result = tmp_path / "result.txt"
+    splits = s2 if world == 2 else s3
+    mp.spawn(_worker, args=(world, _free_port(), case, str(result), splits, True), nprocs=world, join=True)
     assert result.read_text() == "ok"
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r02_artifacts.sh STAGE [TAG] -- regenerates the committed measurement artefacts of a round with the CURRENT
+# tools/artifacts.sh STAGE [TAG] -- regenerates the committed measurement artefacts of a round with the CURRENT
 # binary, on the GPU box (via gpurun); outputs under gpurun_out/<TAG>/, copied to profiles/ by tools/collect_artifacts.py.
 #   bench    : bench.py for every BASELINE config + extras -> bench_all_configs.jsonl
 #   profile  : rocprofv3 kernel-trace/stats + PMC passes for cfg4, cfg5, 8k_444_f1, 8k_420_f1 (tools/profile.sh)
@@ -9,7 +9,7 @@
 #   stripes  : bench.py --stripe-of 2/4/8 -> bench_stripe_of.jsonl
 set -o pipefail
 STAGE=${1:-bench}
-TAG=${2:-r02}
+TAG=${2:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -39,6 +39,14 @@ profile)
     bash tools/profile.sh $TAG $c > "$OUT/profile_$c.log" 2>&1 || { tail -5 "$OUT/profile_$c.log"; exit 1; }
     echo "profiled $c"
   done
+  ;;
+profile_rows)
+  # the weakest shapes: 1000-pixel rows in both order classes next to the aligned 1024 shape
+  bash tools/profile.sh $TAG sq1000_csq --config sq1000 --frames-per-step 1024 > "$OUT/profile_sq1000_csq.log" 2>&1 || { tail -5 "$OUT/profile_sq1000_csq.log"; exit 1; }
+  bash tools/profile.sh $TAG sq1000_scq --config sq1000 --order scq --frames-per-step 1024 > "$OUT/profile_sq1000_scq.log" 2>&1 || { tail -5 "$OUT/profile_sq1000_scq.log"; exit 1; }
+  bash tools/profile.sh $TAG sq1024_scq --config sq1024 --order scq --frames-per-step 1024 > "$OUT/profile_sq1024_scq.log" 2>&1 || { tail -5 "$OUT/profile_sq1024_scq.log"; exit 1; }
+  bash tools/profile.sh $TAG sq1024_csq --config sq1024 --frames-per-step 1024 > "$OUT/profile_sq1024_csq.log" 2>&1 || { tail -5 "$OUT/profile_sq1024_csq.log"; exit 1; }
+  echo "profiled sq1000/sq1024 rows"
   ;;
 small)
   rm -f "$OUT/small_launch.jsonl"

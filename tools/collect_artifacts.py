@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/collect_artifacts.py TAG -- copies what tools/r02_artifacts.sh left under gpurun_out/TAG/ (scratch) into
+"""tools/collect_artifacts.py TAG -- copies what tools/artifacts.sh left under gpurun_out/TAG/ (scratch) into
 profiles/ (tracked) as TAG_<name>, runs tools/pmc_traffic.py for every profiled config, and renders
 profiles/TAG_small_launch.md from the small-launch JSON lines.  Run in the build container after the GPU calls."""
 import collections
@@ -69,7 +69,7 @@ def main():
     if os.path.exists(sl):
         small_launch_md(sl, os.path.join(dst, f"{tag}_small_launch.md"), tag)
         copied.append("small_launch.md (rendered)")
-    for cfg in ("cfg4", "cfg5", "8k_444_f1", "8k_420_f1"):
+    for cfg in ("cfg4", "cfg5", "8k_444_f1", "8k_420_f1", "sq1000_csq", "sq1000_scq", "sq1024_scq", "sq1024_csq"):
         d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}" + ("" if cfg == "cfg4" else f"_{cfg}"))
         if os.path.isdir(d):
             subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), tag, cfg], stdout=subprocess.DEVNULL)

@@ -65,10 +65,13 @@ def main():
     fetch_scale = N / (ck["FETCH_SIZE_mean"] * 1024) if ck and ck["FETCH_SIZE_mean"] else 2.0
     write_scale = N / (sy["WRITE_SIZE_mean"] * 1024) if sy and sy["WRITE_SIZE_mean"] else 1.0
     bench_json = os.path.join(src, "fetch_bench.json")
-    plan_kernel = None
+    plan_kernel, alg_bytes, workload = None, None, None
     if os.path.exists(bench_json):
         try:
-            plan_kernel = json.load(open(bench_json))["config"]["kernel"]
+            line = json.load(open(bench_json))
+            plan_kernel = line["config"]["kernel"]
+            alg_bytes = line["roofline"]["algorithmic_bytes_per_launch"]
+            workload = line["config"]["workload"] + "; " + line["config"]["launch"]
         except Exception:
             pass
     hpath = os.path.join(src, "source_sha256.txt")       # written by tools/profile.sh on the box that ran the profile
@@ -87,6 +90,8 @@ def main():
             "source_sha256": profiled_hash,
             "hbm_read_bytes_per_launch": round(rd), "hbm_write_bytes_per_launch": round(wr),
             "hbm_bytes_per_launch": round(rd + wr),
+            "algorithmic_bytes_per_launch": alg_bytes, "traffic_over_algorithmic": round((rd + wr) / alg_bytes, 4) if alg_bytes else None,
+            "workload": workload,
             "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB units); read side x2 per "
                     "MI355X_MICROARCH.md (gfx950 FETCH_SIZE tallies 128-B requests at 64 B), write side x1; "
                     f"calibrated in the same session on known byte counts: k_checksum read scale {fetch_scale:.4f}, "

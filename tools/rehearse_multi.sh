@@ -23,4 +23,19 @@ timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N
     bench.py --gpus $NP --backend gloo --steps 20 --warmup 5 > "$OUT/${TAG}_multi_rehearsal${SUF}.bench.log" 2>&1
 rc=$?
 tail -n 2 "$OUT/${TAG}_multi_rehearsal${SUF}.bench.log"
+[ $rc -eq 0 ] || exit $rc
+# (c) the same run with the launch engine failing on the LAST rank only, inside the timed region (CSIC_BENCH_INJECT_FAIL, the
+#     hook tests/test_bench_protocol.py drives on the CPU): every rank must finish, with the next issue mode and a note
+ISSUE=direct; [ "$NP" = "2" ] && ISSUE=hip
+CSIC_BENCH_INJECT_FAIL="rank=$((NP-1)),issue=$ISSUE,phase=timed" timeout -k 10 400 python -m torch.distributed.run --nnodes=1 \
+    --nproc-per-node $NP --master-addr 127.0.0.1 --master-port 29520 \
+    bench.py --gpus $NP --backend gloo --steps 20 --warmup 5 --no-side > "$OUT/${TAG}_multi_rehearsal${SUF}.inject.log" 2>&1
+rc=$?
+tail -n 1 "$OUT/${TAG}_multi_rehearsal${SUF}.inject.log" | python -c "
+import json, sys
+l = json.loads(sys.stdin.readline())
+print('inject:', l['config']['issue'], '|', l['config'].get('issue_note'))
+assert l['config']['issue'] != '$ISSUE' and 'failed on 1 rank' in l['config']['issue_note']"
+rc2=$?
+[ $rc -eq 0 ] && exit $rc2
 exit $rc
