@@ -409,7 +409,7 @@ class Workload:
         self.torch.cuda.empty_cache()
 
 
-def timed_run(wl, args, comm, before_timed=None, after_timed=None):
+def timed_run(wl, args, comm, before_timed=None, after_launches=None, after_timed=None):
     """W untimed warm-up steps, then EXACTLY K steps (of args.batch launches each) bracketed by barrier + synchronize on
     both sides.  NEVER raises between its collectives: whatever fails locally (a launch, the engine, a synchronize) is kept
     in a Guard, the rank still enters every barrier and reduction, and the number of failed ranks comes back all-reduced.
@@ -460,6 +460,8 @@ def timed_run(wl, args, comm, before_timed=None, after_timed=None):
             if st != 0:
                 raise RuntimeError("a launch failed inside the timed region")
         ev[1].record(stream)
+        if after_launches:                                        # (--busy-streams: are the other streams still busy when OUR stream is done?)
+            after_launches(stream)
 
     g.run(timed)
     comm.barrier(g)
@@ -683,22 +685,27 @@ def main(argv=None):
         """Enqueue far more copies than the timed region lasts (a 64 MiB copy is ~21 us alone; the host enqueues one in ~3 us,
         so a backlog builds up while this loop runs)."""
         lib = csic._native.lib()
-        est_s = max(0.05, 4.0 * args.steps * args.batch * 40e-6)
-        n = int(min(60000, max(4000, est_s / 21e-6)))
+        per = 64 if args.per_frame_graph else 1                      # launches behind one step() call
+        est_s = max(0.05, 6.0 * args.steps * args.batch * per * 8e-6)
+        n = int(min(120000, max(4000, est_s / 21e-6)))
         for sd, (a_, b_) in zip(busy["streams"], busy["bufs"]):
             sh = C.c_void_p(sd.cuda_stream)
             for i in range(n):
                 lib.csic_copy_device(C.c_void_p((b_ if i & 1 else a_).data_ptr()), C.c_void_p((a_ if i & 1 else b_).data_ptr()), a_.numel(), sh)
         busy["n"] = n
 
+    def busy_probe(launch_stream):
+        launch_stream.synchronize()                                 # OUR launches are done: the others must still be at it
+        busy["still"] = [not sd.query() for sd in busy["streams"]]
+
     def busy_check():
-        still = [not sd.query() for sd in busy["streams"]]
+        still = busy.get("still", [])
         busy["report"] = {"streams": args.busy_streams, "copies_enqueued_per_stream": busy.get("n", 0), "bytes_per_copy": 2 * (64 << 20),
-                          "still_running_after_timed_region": still, "outlasted_timed_region": all(still)}
+                          "still_running_when_the_timed_launches_finished": still, "outlasted_timed_region": bool(still) and all(still)}
         for sd in busy["streams"]:
             sd.synchronize()
 
-    hooks = {"before_timed": busy_start, "after_timed": busy_check} if args.busy_streams > 0 else {}
+    hooks = {"before_timed": busy_start, "after_launches": busy_probe, "after_timed": busy_check} if args.busy_streams > 0 else {}
 
     W, H, a, b, bits, f, _ = CONFIGS[args.config]
     K = args.steps

@@ -15,7 +15,7 @@ from .stages import (ChromaSubsampler, ColorQuantizer, PixelBundle, PixelYCbCrBu
                      SpatialDownsampler, YCbCrUtils, pack_ycc, unpack_ycc)
 from .app import ImageCompressionApp
 from .distributed import MultiDeviceCompressor, Stripe, StripedImageCompressorTop, halo_stripe_for_rank, stripe_for_rank
-from . import app, compressor, distributed, model, params, pipeline, stages
+from . import app, compressor, distributed, model, params, pipeline, stages, stream
 
 __all__ = [
     "CsicIOError", "CsicRuntimeError", "IllegalArgumentException", "ImageProcessorParams", "PixelFormat", "ProcessingStep",

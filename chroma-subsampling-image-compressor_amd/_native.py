@@ -64,6 +64,16 @@ class CsicParams(C.Structure):
     ]
 
 
+class CsicStreamIn(C.Structure):
+    _fields_ = [("in_valid", C.c_int32), ("in_bits", C.c_uint32), ("out_ready", C.c_int32), ("sof", C.c_int32), ("eol", C.c_int32)]
+
+
+class CsicStreamOut(C.Structure):
+    _fields_ = [("in_ready", C.c_int32), ("out_valid", C.c_int32), ("out_bits", C.c_uint32)]
+
+
+STREAM_TOP, STREAM_PROCESSOR, STREAM_RGB2YCBCR, STREAM_CHROMA, STREAM_SPATIAL, STREAM_QUANT = range(6)
+
 # every symbol include/csic.h declares, with its prototype
 PROTOTYPES = {
     "csic_abi_version": (C.c_int, []),
@@ -109,6 +119,15 @@ PROTOTYPES = {
     "csic_pipeline_collect": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]),
     "csic_pipeline_pending": (C.c_int, [C.c_void_p]),
     "csic_pipeline_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
+    "csic_stream_create": (C.c_int, [C.POINTER(CsicParams), C.c_int32, C.POINTER(C.c_void_p)]),
+    "csic_stream_destroy": (C.c_int, [C.c_void_p]),
+    "csic_stream_reset": (C.c_int, [C.c_void_p]),
+    "csic_stream_eval": (C.c_int, [C.c_void_p, C.POINTER(CsicStreamIn), C.POINTER(CsicStreamOut)]),
+    "csic_stream_step": (C.c_int, [C.c_void_p, C.POINTER(CsicStreamIn), C.POINTER(CsicStreamOut)]),
+    "csic_stream_cycles": (C.c_int64, [C.c_void_p]),
+    "csic_stream_depth": (C.c_int, [C.c_void_p]),
+    "csic_stream_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t,
+                                  C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "csic_multi_create": (C.c_int, [C.POINTER(CsicParams), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]),
     "csic_multi_destroy": (C.c_int, [C.c_void_p]),
     "csic_multi_count": (C.c_int, [C.c_void_p]),

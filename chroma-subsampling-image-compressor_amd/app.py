@@ -27,8 +27,17 @@ class ImageCompressionApp:
                      chromaParamA: int, chromaParamB: int,
                      yTargetBits: int, cbTargetBits: int, crTargetBits: int,
                      spatialFactorToUse: int,
-                     op1: ProcessingStep, op2: ProcessingStep, op3: ProcessingStep, *, device: int = 0) -> None:
-        """ImageCompressorTopApp.scala:23-145."""
+                     op1: ProcessingStep, op2: ProcessingStep, op3: ProcessingStep, *, device: int = 0,
+                     emulateCollectorBudget: bool = False) -> None:
+        """ImageCompressorTopApp.scala:23-145.
+
+        emulateCollectorBudget: the reference's collector loop gives up after (W/f)*(H/f)*40 + 10000 simulated cycles (:110)
+        and the pixels it did not get keep the image's magenta fill (:133-141).  ImageCompressorTop accepts one pixel every
+        two cycles (three non-pipe Queue(1)s), so that budget is too small for sf = 8 on anything larger than ~85x85 --
+        including the app's own defaults (in128x128.png, sf = 8: 160 of 256 pixels).  Off (default), every pixel is
+        written; on, the cycle-level model (stream.ImageCompressorTop) is asked how many pixels the collector would have
+        got and the rest stays magenta, which is what a run of the reference app is predicted to produce.  The pixel
+        VALUES come from the GPU either way; the model contributes a count."""
         inputImage = ImageProcessorModel.readImage(inputImagePath)
         W, H = inputImage.width, inputImage.height
         f = spatialFactorToUse
@@ -45,6 +54,13 @@ class ImageCompressionApp:
         # The harness collects the first finalW*finalH pixels of the OUTPUT STREAM and lays them out
         # finalW per row (:108-124, :133-142); identical to `out` when the dimensions divide.
         stream = out.reshape(-1)[: finalW * finalH]
+        if emulateCollectorBudget:
+            from .stream import ImageCompressorTop as CycleModel
+            with CycleModel(W, H, chromaParamA, chromaParamB, yTargetBits, cbTargetBits, crTargetBits, f, op1, op2, op3) as dut:
+                got, _ = dut.run(inputImage.argb, max_out=finalW * finalH, max_cycles=dut.collection_budget())
+            if got.size < finalW * finalH:
+                print(f"[WARN] Output collection timed out. Collected {got.size} out of {finalW * finalH} pixels.")    # :126-128
+            stream = stream[: got.size]
         if stream.size < finalW * finalH:
             pad = np.full(finalW * finalH - stream.size, 0xFFFF00FF, dtype=np.uint32)   # AwtColor.MAGENTA fill, :133
             stream = np.concatenate([stream, pad])
@@ -128,7 +144,9 @@ def main(argv: List[str] = None) -> int:
     if not os.path.exists(inputPath):
         print(f"[ERROR] Input image not found: {inputPath}")          # :197-199 (not an exception)
         return 0
-    ImageCompressionApp.processImage(inputPath, outputPath, a, b, yq, cbq, crq, sf, op1, op2, op3)
+    # not a key of the reference's CLI: `--collector-budget emulate` reproduces its collector's cycle budget (see processImage)
+    emulate = argsMap.get("--collector-budget", "off") == "emulate"
+    ImageCompressionApp.processImage(inputPath, outputPath, a, b, yq, cbq, crq, sf, op1, op2, op3, emulateCollectorBudget=emulate)
     print(f"Image processing complete. Output saved to: {outputPath}")
     return 0
 

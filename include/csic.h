@@ -371,6 +371,55 @@ int  csic_pipeline_pending(const csic_pipeline *pipeline);
 #define CSIC_PIPELINE_ZERO_COPY 1
 int  csic_pipeline_set_mode(csic_pipeline *pipeline, int32_t mode);
 
+/* ---- cycle-level model of the Decoupled pixel stream (host only) ---------------------------
+ * What the reference's users simulate is not a function from frames to frames but hardware: modules that exchange one
+ * pixel per ready/valid handshake (ImageCompressorTop.scala:33-38), and its tests check the handshake as well as the
+ * pixels (back-pressure: SpatialDownsamplerSpec.scala:48-58; the cycle budget of the app's collector:
+ * ImageCompressorTopApp.scala:110).  A csic_stream is that interface, clock edge by clock edge, for
+ *   CSIC_STREAM_TOP        class ImageCompressorTop: RGB2YCbCr -> Queue(1) -> op1 -> Queue(1) -> op2 -> Queue(1) -> op3
+ *                          (ImageCompressorTop.scala:63-65,80-114; the queues are chisel3.util.Queue, pipe = flow = false)
+ *   CSIC_STREAM_PROCESSOR  class ImageProcessor: RGB2YCbCr -> ChromaSubsampler -> SpatialDownsampler, no queues
+ *                          (ImageProcessor.scala:42-62)
+ *   CSIC_STREAM_RGB2YCBCR / _CHROMA / _SPATIAL / _QUANT   one module alone, as the reference's specs drive it
+ * built from the same csic_params (and rejected by the same require()s; FLOOR_HW and HOLD_DECIMATE only: the RTL has no
+ * other rounding or sampling).  in_bits is a PixelBundle (CSIC_FMT_ARGB8888) where the chain starts with RGB2YCbCr, else
+ * a PixelYCbCrBundle (CSIC_FMT_YCBCR888X); out_bits is the PixelYCbCrBundle on io.out, or -- params.out_format ==
+ * CSIC_FMT_ARGB8888 -- that pixel put through YCbCrUtils.ycbcr2rgb as the harness does (ImageCompressorTopApp.scala:118).
+ * sof / eol are accepted and, as in the RTL (SpatialDownsampler.scala:11-12), read by no logic.
+ *
+ * This is a simulator of interface timing (a few Mpixel/s on one host core), NOT a compute path: no csic_process_* /
+ * csic_plan_* / csic_frame_graph_* call ever reaches it, and they still fail with CSIC_ENODEVICE without a GPU.  RTL /
+ * FIRRTL emission would need Chisel and is out of scope.
+ *
+ *   csic_stream_eval : the combinational outputs (in_ready, out_valid, out_bits) for the present state and inputs -- a
+ *                      chiseltest peek(); the state does not change.
+ *   csic_stream_step : the same outputs (may be NULL), then one rising clock edge -- poke(...); clock.step().
+ *   csic_stream_run  : the reference harness's two loops in one call (ImageCompressorTopApp.scala:76-124): the driver keeps
+ *                      a pixel on the wires until the edge at which in_ready is high, the collector takes a pixel at every
+ *                      edge where out_valid && out_ready and stops after max_out pixels or max_cycles cycles (< 0: until the
+ *                      input is used up and the pipeline has drained).  in_valid_pattern / out_ready_pattern (cyclic over
+ *                      the cycle number, NULL = always 1) add producer gaps and back-pressure.  *n_out pixels were
+ *                      collected in *cycles cycles; the stream's state carries over to the next call. */
+#define CSIC_STREAM_TOP        0
+#define CSIC_STREAM_PROCESSOR  1
+#define CSIC_STREAM_RGB2YCBCR  2
+#define CSIC_STREAM_CHROMA     3
+#define CSIC_STREAM_SPATIAL    4
+#define CSIC_STREAM_QUANT      5
+typedef struct csic_stream csic_stream;
+typedef struct csic_stream_in  { int32_t in_valid; uint32_t in_bits; int32_t out_ready; int32_t sof, eol; } csic_stream_in;
+typedef struct csic_stream_out { int32_t in_ready; int32_t out_valid; uint32_t out_bits; } csic_stream_out;
+int     csic_stream_create(const csic_params *p, int32_t kind, csic_stream **out);
+int     csic_stream_destroy(csic_stream *stream);
+int     csic_stream_reset(csic_stream *stream);                       /* every register back to its RegInit value, cycle count 0 */
+int     csic_stream_eval(const csic_stream *stream, const csic_stream_in *in, csic_stream_out *out);
+int     csic_stream_step(csic_stream *stream, const csic_stream_in *in, csic_stream_out *out);
+int64_t csic_stream_cycles(const csic_stream *stream);                /* clock edges since creation / reset */
+int     csic_stream_depth(const csic_stream *stream);                 /* modules in the chain (queues included): 7 for TOP */
+int     csic_stream_run(csic_stream *stream, const uint32_t *in, size_t n_in, uint32_t *out, size_t max_out, int64_t max_cycles,
+                        const uint8_t *in_valid_pattern, size_t in_pattern_len,
+                        const uint8_t *out_ready_pattern, size_t out_pattern_len, size_t *n_out, int64_t *cycles);
+
 /* ---- several devices from one process --------------------------------------------------------------
  * The same aligned row-stripe partition as csic_stripe_rows, for hosts that own all GPUs in ONE process
  * (a JVM, a C++ service); bench.py and the Python driver use one process per GPU instead.  Stripe i runs on

@@ -183,6 +183,34 @@ private:
     csic_frame_graph *g_ = nullptr;
 };
 
+// Cycle-level model of the Decoupled pixel stream (csic_stream_*): the generated hardware's ready/valid interface, one clock
+// edge per step() -- chiseltest's poke / peek / step on the reference's modules (SpatialDownsamplerSpec.scala:48-58).  Host only;
+// a simulator of interface timing, never a compute path.
+class StreamModel {
+public:
+    StreamModel(const csic_params &p, int32_t kind) { check(csic_stream_create(&p, kind, &s_)); }
+    StreamModel(const StreamModel &) = delete;
+    StreamModel &operator=(const StreamModel &) = delete;
+    ~StreamModel() { csic_stream_destroy(s_); }
+    csic_stream_in in{0, 0, 0, 0, 0};                                       // poked inputs hold their value (un-poked: 0)
+    csic_stream_out peek() const { csic_stream_out o; check(csic_stream_eval(s_, &in, &o)); return o; }
+    csic_stream_out step() { csic_stream_out o; check(csic_stream_step(s_, &in, &o)); return o; }
+    void reset() { check(csic_stream_reset(s_)); in = csic_stream_in{0, 0, 0, 0, 0}; }
+    int64_t cycles() const { return csic_stream_cycles(s_); }
+    // the app's driver + collector loops (ImageCompressorTopApp.scala:76-124); max_cycles < 0 = until drained
+    std::vector<uint32_t> run(const std::vector<uint32_t> &pixels, size_t max_out, int64_t max_cycles = -1, int64_t *cycles_used = nullptr)
+    {
+        std::vector<uint32_t> out(max_out ? max_out : 1);
+        size_t n = 0;
+        check(csic_stream_run(s_, pixels.data(), pixels.size(), out.data(), max_out, max_cycles, nullptr, 0, nullptr, 0, &n, cycles_used));
+        out.resize(n);
+        return out;
+    }
+
+private:
+    csic_stream *s_ = nullptr;
+};
+
 class ImageProcessor : public ImageCompressorTop {
 public:
     explicit ImageProcessor(const ImageProcessorParams &p, Rounding rounding = Rounding::FLOOR_HW, int device = 0)

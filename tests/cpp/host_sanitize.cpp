@@ -74,9 +74,67 @@ static int check_magic_div()
     return 0;
 }
 
+// the cycle-level stream model: every kind, random shapes and orders, random producer gaps and back-pressure; the collected stream
+// must not depend on the handshakes, and eval / step must agree with run
+static int check_stream_model()
+{
+    long runs = 0;
+    for (int it = 0; it < 300; ++it) {
+        csic_params p; csic_params_default(&p, 1 + rnd() % 33, 1 + rnd() % 17);
+        const int ab[5][2] = {{4, 4}, {2, 2}, {2, 0}, {1, 1}, {1, 0}};
+        const int perms[6][3] = {{1, 2, 3}, {1, 3, 2}, {2, 1, 3}, {2, 3, 1}, {3, 1, 2}, {3, 2, 1}};
+        const int k = rnd() % 5;
+        p.chroma_a = ab[k][0]; p.chroma_b = ab[k][1];
+        p.factor = 1 << (rnd() % 4);
+        p.y_bits = 1 + rnd() % 8; p.cb_bits = 1 + rnd() % 8; p.cr_bits = 1 + rnd() % 8;
+        std::memcpy(p.op, perms[rnd() % 6], sizeof p.op);
+        p.out_format = rnd() % 2;
+        const int kind = rnd() % 6;
+        if (kind >= CSIC_STREAM_CHROMA) p.in_format = CSIC_FMT_YCBCR888X;
+        csic_stream *s = nullptr;
+        if (csic_stream_create(&p, kind, &s) != 0) { std::printf("stream create failed: %s\n", csic_last_error()); return 1; }
+        const size_t n = (size_t)p.width * p.height;
+        std::vector<uint32_t> in(n), a(n + 1), b(n + 1);
+        for (auto &v : in) v = rnd();
+        size_t na = 0, nb = 0; int64_t ca = 0, cb = 0;
+        if (csic_stream_run(s, in.data(), n, a.data(), n, -1, nullptr, 0, nullptr, 0, &na, &ca) != 0) return 1;
+        uint8_t pv[7], pr[5];
+        for (auto &v : pv) v = rnd() & 1;
+        for (auto &v : pr) v = rnd() & 1;
+        pv[rnd() % 7] = 1; pr[rnd() % 5] = 1;
+        csic_stream_reset(s);
+        if (csic_stream_run(s, in.data(), n, b.data(), n, -1, pv, 7, pr, 5, &nb, &cb) != 0) return 1;
+        if (na != nb || std::memcmp(a.data(), b.data(), na * 4) != 0 || cb < ca) { std::printf("stream depends on the handshakes\n"); return 1; }
+        // the same through eval + step
+        csic_stream_reset(s);
+        size_t fed = 0, got = 0;
+        for (int64_t c = 0; c < cb + 8 && got < na; ++c) {
+            csic_stream_in pin{fed < n && pv[c % 7] ? 1 : 0, fed < n ? in[fed] : 0u, pr[c % 5] ? 1 : 0, 0, (int32_t)(rnd() & 1)};
+            csic_stream_out o1, o2;
+            if (csic_stream_eval(s, &pin, &o1) != 0 || csic_stream_step(s, &pin, &o2) != 0) return 1;
+            if (o1.in_ready != o2.in_ready || o1.out_valid != o2.out_valid || (o1.out_valid && o1.out_bits != o2.out_bits)) { std::printf("eval != step\n"); return 1; }
+            if (o1.out_valid && pin.out_ready) { if (o1.out_bits != a[got]) { std::printf("step stream differs at %zu\n", got); return 1; } ++got; }
+            if (pin.in_valid && o1.in_ready) ++fed;
+        }
+        if (got != na || csic_stream_cycles(s) <= 0 || csic_stream_depth(s) < 1) { std::printf("step stream incomplete\n"); return 1; }
+        uint8_t zero = 0;
+        if (csic_stream_run(s, in.data(), n, b.data(), n, -1, nullptr, 0, &zero, 1, &nb, &cb) == 0) { std::printf("all-zero ready pattern accepted\n"); return 1; }
+        csic_stream_destroy(s);
+        ++runs;
+    }
+    csic_params bad; csic_params_default(&bad, 8, 8);
+    bad.rounding = CSIC_ROUND_TRUNC_SW;
+    csic_stream *s = nullptr;
+    if (csic_stream_create(&bad, CSIC_STREAM_TOP, &s) != CSIC_EINVAL_ROUNDING || s) { std::printf("TRUNC_SW accepted by the RTL model\n"); return 1; }
+    if (csic_stream_create(&bad, 9, &s) == 0 || csic_stream_create(nullptr, 0, &s) == 0 || csic_stream_step(nullptr, nullptr, nullptr) == 0) return 1;
+    std::printf("stream model: %ld random configurations\n", runs);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (check_magic_div()) return 1;
+    if (check_stream_model()) return 1;
     // ---- validation / geometry / stripes over a grid of good and bad parameters
     long checked = 0;
     for (int W : {-1, 0, 1, 5, 16, 8192, 65536}) for (int H : {0, 1, 3, 4096, 40000})

@@ -140,9 +140,36 @@ static void png_checks(const char *in_png)
     EXPECT(io);
 }
 
+// the back-pressure KAT of SpatialDownsamplerSpec.scala:48-58 and a 4x4 frame through ImageCompressorTop, from C++
+static void stream_model_checks()
+{
+    csic_params p;
+    csic_params_default(&p, 4, 4);
+    p.factor = 2;
+    p.in_format = p.out_format = CSIC_FMT_YCBCR888X;
+    StreamModel dut(p, CSIC_STREAM_SPATIAL);
+    dut.in.out_ready = 0; dut.step();
+    EXPECT(dut.peek().in_ready == 0);
+    dut.in.out_ready = 1; dut.step();
+    EXPECT(dut.peek().in_ready == 1 && dut.cycles() == 2);
+    csic_params t;
+    csic_params_default(&t, 4, 4);
+    t.factor = 2; t.out_format = CSIC_FMT_YCBCR888X;
+    StreamModel top(t, CSIC_STREAM_TOP);
+    std::vector<uint32_t> px(16, 0xFFFFFFFFu);                        // white: (255, 128, 128) -- RGB2YCbCrTester.scala:13
+    int64_t cyc = 0;
+    const std::vector<uint32_t> out = top.run(px, 16, -1, &cyc);
+    EXPECT(out.size() == 4 && out[0] == (255u | (128u << 8) | (128u << 16)) && cyc >= 2 * 16 - 2);
+    bool iae = false;
+    t.factor = 3;
+    try { StreamModel bad(t, CSIC_STREAM_TOP); } catch (const IllegalArgumentException &e) { iae = e.status == CSIC_EINVAL_FACTOR; }
+    EXPECT(iae);
+}
+
 int main(int argc, char **argv)
 {
     cpu_checks();
+    stream_model_checks();
     device_guard_checks();
     if (argc > 2) png_checks(argv[2]);
     if (argc > 1 && std::strcmp(argv[1], "gpu") == 0) {
