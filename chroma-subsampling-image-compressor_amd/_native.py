@@ -64,6 +64,12 @@ class CsicParams(C.Structure):
     ]
 
 
+class CsicFilesStats(C.Structure):
+    _fields_ = [("frames", C.c_int64), ("wall_s", C.c_double), ("decode_s", C.c_double), ("encode_s", C.c_double),
+                ("gpu_wait_s", C.c_double), ("slot_wait_s", C.c_double), ("decode_threads", C.c_int32), ("encode_threads", C.c_int32),
+                ("slots", C.c_int32), ("max_in_flight", C.c_int32), ("in_pixels", C.c_int64), ("out_pixels", C.c_int64)]
+
+
 class CsicStreamIn(C.Structure):
     _fields_ = [("in_valid", C.c_int32), ("in_bits", C.c_uint32), ("out_ready", C.c_int32), ("sof", C.c_int32), ("eol", C.c_int32)]
 
@@ -119,6 +125,8 @@ PROTOTYPES = {
     "csic_pipeline_collect": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int64)]),
     "csic_pipeline_pending": (C.c_int, [C.c_void_p]),
     "csic_pipeline_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
+    "csic_process_png_files": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, C.POINTER(CsicFilesStats)]),
     "csic_stream_create": (C.c_int, [C.POINTER(CsicParams), C.c_int32, C.POINTER(C.c_void_p)]),
     "csic_stream_destroy": (C.c_int, [C.c_void_p]),
     "csic_stream_reset": (C.c_int, [C.c_void_p]),

@@ -71,23 +71,52 @@ class ImageCompressionApp:
     def processImages(inputImagePaths, outputImagePaths, chromaParamA: int, chromaParamB: int,
                       yTargetBits: int, cbTargetBits: int, crTargetBits: int, spatialFactorToUse: int,
                       op1: ProcessingStep, op2: ProcessingStep, op3: ProcessingStep, *, device: int = 0,
-                      depth: int = 3) -> None:
-        """Many same-sized images through one plan and a FramePipeline: PNGs are decoded straight into
-        pinned staging, and H2D / kernel / D2H of neighbouring images overlap.  Output files are what
-        processImage would write for each input."""
-        from .pipeline import FramePipeline
+                      depth: int = 3, decodeThreads: int = None, encodeThreads: int = None, compression: int = 6):
+        """Many same-sized images through one plan.  Output files are what processImage would write for each input.
+
+        Default: csic_process_png_files -- pools of decoder and encoder threads inside the library (no GIL) around
+        pinned frame slots; a decoder inflates a PNG straight into a slot and launches the kernel on the slot's stream,
+        an encoder waits for the slot and writes the output file.  decodeThreads / encodeThreads = None: the library's
+        choice; returns the call's csic_files_stats as a dict.
+        decodeThreads=0: the serial reference flow of round 2 -- this thread decodes into a FramePipeline slot, submits,
+        collects and encodes, one image after the other (only H2D / kernel / D2H of neighbouring images overlap); kept
+        as the baseline the pooled path is byte-compared against (tests/test_gpu_parity.py)."""
+        import ctypes as C
+        from . import _native as N
         W, H = ImageProcessorModel.imageSize(inputImagePaths[0])
         f = spatialFactorToUse
         top = ImageCompressorTop(W, H, chromaParamA, chromaParamB, yTargetBits, cbTargetBits, crTargetBits,
                                  f, op1, op2, op3, device=device)
         finalW, finalH = W // f, H // f
+        for path in outputImagePaths:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)     # outputFile.getParentFile().mkdirs(), ImageProcessorModel.scala:20
+        if decodeThreads == 0:
+            ImageCompressionApp._processImagesSerial(top, inputImagePaths, outputImagePaths, finalW, finalH, depth, compression)
+            top.close()
+            return None
+        n = len(inputImagePaths)
+        if n != len(outputImagePaths):
+            raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: need as many output as input paths")
+        ins = (C.c_char_p * n)(*[os.fsencode(p) for p in inputImagePaths])
+        outs = (C.c_char_p * n)(*[os.fsencode(p) for p in outputImagePaths])
+        st = N.CsicFilesStats()
+        try:
+            N.check(N.lib().csic_process_png_files(top.plan()._h, ins, outs, n, decodeThreads or 0, encodeThreads or 0, compression,
+                                                   finalW, finalH, C.byref(st)))
+        finally:
+            top.close()
+        return {k: getattr(st, k) for k, _ in N.CsicFilesStats._fields_}
+
+    @staticmethod
+    def _processImagesSerial(top, inputImagePaths, outputImagePaths, finalW, finalH, depth, compression):
+        from .pipeline import FramePipeline
         todo = list(outputImagePaths)
 
         def write(stream_frame, path):
             stream = stream_frame.reshape(-1)[: finalW * finalH]
             if stream.size < finalW * finalH:
                 stream = np.concatenate([stream, np.full(finalW * finalH - stream.size, 0xFFFF00FF, dtype=np.uint32)])
-            ImageProcessorModel.writeImage(Image(stream.reshape(finalH, finalW).copy()), path)
+            ImageProcessorModel.writeImage(Image(stream.reshape(finalH, finalW).copy()), path, compression=compression)
 
         with FramePipeline(top.plan(), depth) as pipe:
             done = 0
@@ -99,7 +128,6 @@ class ImageCompressionApp:
                 pipe.submit()
             while pipe.pending:
                 write(pipe.collect()[1], todo[done]); done += 1
-        top.close()
 
 
 def _order_tag(step: ProcessingStep) -> str:

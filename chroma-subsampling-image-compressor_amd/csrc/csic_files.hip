@@ -1,0 +1,265 @@
+// csic_files.hip -- PNG files in, PNG files out: the frame pipeline with the codec on worker threads.
+//
+// The reference handles one image at a time on one thread: readImage -> per-pixel poke ... peek -> writeImage
+// (ImageProcessorModel.scala:14-52, ImageCompressorTopApp.scala:39-41,133-144).  Once the kernel runs at the HBM roofline the
+// PNG codec is everything: one host thread decodes a 4K frame at ~160 Mpixel/s and encodes at ~50, the kernel moves
+// 4.8 Tpixel/s (profiles/r02_host_io.json).  So the step either side of the path is a pool: `decode_threads` workers inflate
+// files STRAIGHT INTO pinned frame slots and launch the fused kernel on the slot's own stream (zero-copy: it reads the pinned
+// frame over PCIe and writes the pinned result, dead rows never cross the bus), `encode_threads` workers wait for a slot's
+// event and deflate its result to the output file.  Slots are the bounded queue between the two pools: a decoder that finds
+// no free slot waits for an encoder to release one.  Files are independent, so frames finish in whatever order the workers
+// allow; every output file is byte for byte what the serial path (csic_png_read_argb -> csic_pipeline_* -> csic_png_write_argb,
+// one thread) writes for the same input, because codec, level and pixels are the same.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "csic_hip_common.h"
+
+using namespace csic;
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+inline double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+struct Slot {
+    uint32_t *h_in = nullptr, *h_out = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+};
+
+struct Shared {
+    csic_plan *plan = nullptr;
+    int device = 0;
+    size_t in_px = 0, out_px = 0, final_px = 0;
+    int32_t final_w = 0, final_h = 0, out_w = 0, out_h = 0, level = 6;
+    const char *const *in_paths = nullptr;
+    const char *const *out_paths = nullptr;
+    int32_t n = 0;
+    std::vector<Slot> slots;
+
+    std::mutex mu;
+    std::condition_variable cv_free, cv_work;
+    std::deque<int> free_slots;
+    std::deque<std::pair<int, int>> inflight;     // (slot, file index), oldest first
+    int decoders_running = 0;
+    std::atomic<int> next_file{0};
+    std::atomic<bool> failed{false};
+    int status = CSIC_OK;
+    std::string message;
+    std::mutex launch_mu;                         // a plan is not thread-safe: launches take turns (the enqueue is microseconds)
+    // accounting (under mu)
+    double decode_s = 0, encode_s = 0, gpu_wait_s = 0, slot_wait_s = 0;
+    int64_t done_files = 0;
+    int max_inflight = 0;
+};
+
+void fail(Shared &sh, int status, const std::string &msg)
+{
+    std::lock_guard<std::mutex> lk(sh.mu);
+    if (!sh.failed.exchange(true)) { sh.status = status; sh.message = msg; }
+    sh.cv_free.notify_all();
+    sh.cv_work.notify_all();
+}
+
+void decoder(Shared &sh)
+{
+    if (hipSetDevice(sh.device) != hipSuccess) { fail(sh, CSIC_EHIP, "decoder thread: cannot make the plan's device current"); }
+    double t_dec = 0, t_wait = 0;
+    while (!sh.failed.load()) {
+        const int i = sh.next_file.fetch_add(1);
+        if (i >= sh.n) break;
+        int slot = -1;
+        {
+            const auto w0 = Clock::now();
+            std::unique_lock<std::mutex> lk(sh.mu);
+            sh.cv_free.wait(lk, [&] { return !sh.free_slots.empty() || sh.failed.load(); });
+            if (sh.failed.load()) break;
+            slot = sh.free_slots.front();
+            sh.free_slots.pop_front();
+            t_wait += secs(w0, Clock::now());
+        }
+        Slot &s = sh.slots[slot];
+        const auto d0 = Clock::now();
+        int st = csic_png_read_argb(sh.in_paths[i], s.h_in, sh.in_px);             // straight into pinned memory
+        t_dec += secs(d0, Clock::now());
+        if (st != CSIC_OK) { fail(sh, st, std::string("file ") + std::to_string(i) + ": " + csic_last_error()); break; }
+        {
+            std::lock_guard<std::mutex> lk(sh.launch_mu);
+            st = launch_on_stream(sh.plan, s.h_in, s.h_out, 1, s.stream);
+            if (st == CSIC_OK && hipEventRecord(s.done, s.stream) != hipSuccess) st = set_error(CSIC_EHIP, "hipEventRecord failed");
+        }
+        if (st != CSIC_OK) { fail(sh, st, std::string("file ") + std::to_string(i) + ": " + csic_last_error()); break; }
+        {
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.inflight.emplace_back(slot, i);
+            if ((int)sh.inflight.size() > sh.max_inflight) sh.max_inflight = (int)sh.inflight.size();
+        }
+        sh.cv_work.notify_one();
+    }
+    std::lock_guard<std::mutex> lk(sh.mu);
+    sh.decode_s += t_dec;
+    sh.slot_wait_s += t_wait;
+    if (--sh.decoders_running == 0) sh.cv_work.notify_all();
+}
+
+void encoder(Shared &sh)
+{
+    if (hipSetDevice(sh.device) != hipSuccess) { fail(sh, CSIC_EHIP, "encoder thread: cannot make the plan's device current"); }
+    double t_enc = 0, t_gpu = 0;
+    int64_t files = 0;
+    std::vector<uint32_t> cropped;
+    for (;;) {
+        int slot = -1, i = -1;
+        {
+            std::unique_lock<std::mutex> lk(sh.mu);
+            sh.cv_work.wait(lk, [&] { return !sh.inflight.empty() || sh.decoders_running == 0 || sh.failed.load(); });
+            if (sh.inflight.empty()) break;                                        // producers are done (or failed) and nothing is queued
+            slot = sh.inflight.front().first;
+            i = sh.inflight.front().second;
+            sh.inflight.pop_front();
+        }
+        Slot &s = sh.slots[slot];
+        const auto g0 = Clock::now();
+        const hipError_t e = hipEventSynchronize(s.done);                          // (also on the failure path: the slot must be idle before it is freed)
+        t_gpu += secs(g0, Clock::now());
+        if (e != hipSuccess) fail(sh, CSIC_EHIP, std::string("file ") + std::to_string(i) + ": hipEventSynchronize failed: " + hipGetErrorString(e));
+        if (!sh.failed.load()) {
+            const auto e0 = Clock::now();
+            const uint32_t *src = s.h_out;
+            if (sh.final_w != sh.out_w || sh.final_h != sh.out_h) {
+                // what the reference's collector keeps: the first final_w * final_h pixels of the output STREAM, laid out final_w
+                // per row; pixels it never got stay magenta (ImageCompressorTopApp.scala:108-124, :133-142)
+                cropped.assign(sh.final_px, 0xFFFF00FFu);
+                const size_t keep = sh.out_px < sh.final_px ? sh.out_px : sh.final_px;
+                std::memcpy(cropped.data(), s.h_out, keep * 4);
+                src = cropped.data();
+            }
+            const int st = csic_png_write_argb(sh.out_paths[i], src, sh.final_w, sh.final_h, sh.level);
+            t_enc += secs(e0, Clock::now());
+            if (st != CSIC_OK) fail(sh, st, std::string("file ") + std::to_string(i) + ": " + csic_last_error());
+            else ++files;
+        }
+        {
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.free_slots.push_back(slot);
+        }
+        sh.cv_free.notify_one();
+    }
+    std::lock_guard<std::mutex> lk(sh.mu);
+    sh.encode_s += t_enc;
+    sh.gpu_wait_s += t_gpu;
+    sh.done_files += files;
+}
+
+} // namespace
+
+extern "C" {
+
+int csic_process_png_files(csic_plan *plan, const char *const *in_paths, const char *const *out_paths, int32_t nfiles,
+                           int32_t decode_threads, int32_t encode_threads, int32_t png_level, int32_t final_width, int32_t final_height,
+                           csic_files_stats *stats)
+{
+    if (!plan || !in_paths || !out_paths) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
+    if (nfiles < 1) return set_error(CSIC_EINVAL_SIZE, "nfiles must be positive. Got %d", nfiles);
+    for (int i = 0; i < nfiles; ++i)
+        if (!in_paths[i] || !out_paths[i]) return set_error(CSIC_EINVAL_NULL, "file %d: path is NULL", i);
+    if (png_level < 0 || png_level > 9) return set_error(CSIC_EINVAL_SIZE, "png_level must be in 0..9. Got %d", png_level);
+    Shared sh;
+    sh.plan = plan;
+    sh.device = plan_device(plan);
+    plan_sizes(plan, &sh.in_px, &sh.out_px);
+    plan_out_dims(plan, &sh.out_w, &sh.out_h);
+    sh.final_w = final_width > 0 ? final_width : sh.out_w;
+    sh.final_h = final_height > 0 ? final_height : sh.out_h;
+    sh.final_px = (size_t)sh.final_w * (size_t)sh.final_h;
+    sh.level = png_level;
+    sh.in_paths = in_paths; sh.out_paths = out_paths; sh.n = nfiles;
+    // the files must be frames of this plan: checked up front so that a wrong batch fails before any thread starts
+    for (int i = 0; i < nfiles; ++i) {
+        int32_t w = 0, h = 0;
+        const int st = csic_png_info(in_paths[i], &w, &h);
+        if (st != CSIC_OK) return st;
+        if ((size_t)w * (size_t)h != sh.in_px || w != plan_width(plan))
+            return set_error(CSIC_EINVAL_SIZE, "%s is %dx%d, the plan processes %dx%zu frames", in_paths[i], w, h, plan_width(plan),
+                             sh.in_px / (size_t)plan_width(plan));
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 4;
+    int D = decode_threads > 0 ? decode_threads : (int)(hw < 32 ? hw : 32);
+    int E = encode_threads > 0 ? encode_threads : (int)(hw < 16 ? hw : 16);
+    if (D > nfiles) D = nfiles;
+    if (E > nfiles) E = nfiles;
+    if (D > 256) D = 256;
+    if (E > 256) E = 256;
+    // slots: one per worker plus two in flight on the GPU, within 8 GiB of pinned memory
+    const size_t slot_bytes = (sh.in_px + sh.out_px) * 4;
+    size_t S = (size_t)D + (size_t)E + 2;
+    const size_t cap = ((size_t)8 << 30) / (slot_bytes ? slot_bytes : 1);
+    if (S > cap) S = cap < 2 ? 2 : cap;
+    if (S > (size_t)nfiles + 1) S = (size_t)nfiles + 1;
+    if ((size_t)D > S) D = (int)S;
+
+    CSIC_DEVICE_SCOPE(sh.device);
+    try { sh.slots.resize(S); } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
+    hipError_t e = hipSuccess;
+    for (auto &s : sh.slots) {
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_in), sh.in_px * 4, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_out), sh.out_px * 4, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+    }
+    auto release = [&] {
+        for (auto &s : sh.slots) {
+            if (s.stream) (void)hipStreamSynchronize(s.stream);
+            if (s.done) (void)hipEventDestroy(s.done);
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+            if (s.h_in) (void)hipHostFree(s.h_in);
+            if (s.h_out) (void)hipHostFree(s.h_out);
+        }
+    };
+    if (e != hipSuccess) {
+        release();
+        return set_error(e == hipErrorOutOfMemory ? CSIC_ENOMEM : CSIC_EHIP, "frame-slot allocation failed: %s", hipGetErrorString(e));
+    }
+    for (size_t k = 0; k < S; ++k) sh.free_slots.push_back((int)k);
+    sh.decoders_running = D;
+
+    const auto t0 = Clock::now();
+    std::vector<std::thread> pool;
+    try {
+        for (int k = 0; k < D; ++k) pool.emplace_back(decoder, std::ref(sh));
+        for (int k = 0; k < E; ++k) pool.emplace_back(encoder, std::ref(sh));
+    } catch (...) {
+        // could not start every worker: the ones that exist must still come to an end
+        {
+            std::lock_guard<std::mutex> lk(sh.mu);
+            const int started_dec = (int)pool.size() < D ? (int)pool.size() : D;
+            sh.decoders_running -= D - started_dec;
+        }
+        fail(sh, CSIC_ENOMEM, "could not start the worker threads");
+    }
+    for (auto &t : pool) t.join();
+    const double wall = secs(t0, Clock::now());
+    release();
+    if (stats) {
+        stats->frames = sh.done_files;
+        stats->wall_s = wall;
+        stats->decode_s = sh.decode_s; stats->encode_s = sh.encode_s; stats->gpu_wait_s = sh.gpu_wait_s; stats->slot_wait_s = sh.slot_wait_s;
+        stats->decode_threads = D; stats->encode_threads = E; stats->slots = (int32_t)S; stats->max_in_flight = sh.max_inflight;
+        stats->in_pixels = (int64_t)sh.in_px * sh.done_files; stats->out_pixels = (int64_t)sh.final_px * sh.done_files;
+    }
+    if (sh.failed.load()) return set_error(sh.status, "%s", sh.message.c_str());
+    clear_error();
+    return CSIC_OK;
+}
+
+} // extern "C"

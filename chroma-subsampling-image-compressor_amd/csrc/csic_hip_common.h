@@ -68,6 +68,8 @@ int enqueue(const LaunchDesc &d, hipStream_t stream);
 int launch_on_stream(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream);
 int plan_device(const csic_plan *pl);
 void plan_sizes(const csic_plan *pl, size_t *in_px, size_t *out_px);
+int32_t plan_width(const csic_plan *pl);
+void plan_out_dims(const csic_plan *pl, int32_t *wo, int32_t *ho);
 int64_t plan_algorithmic_bytes(const csic_plan *pl);          // per frame (csic_algorithmic_bytes of the plan's parameters)
 
 } // namespace csic

@@ -988,6 +988,12 @@ void plan_sizes(const csic_plan *pl, size_t *in_px, size_t *out_px)
     *in_px = (size_t)pl->g.W * pl->g.H;
     *out_px = (size_t)pl->g.Wo * pl->g.Ho;
 }
+int32_t plan_width(const csic_plan *pl) { return pl->g.W; }
+void plan_out_dims(const csic_plan *pl, int32_t *wo, int32_t *ho)
+{
+    *wo = pl->g.Wo;
+    *ho = pl->g.Ho;
+}
 
 } // namespace csic
 

@@ -371,6 +371,30 @@ int  csic_pipeline_pending(const csic_pipeline *pipeline);
 #define CSIC_PIPELINE_ZERO_COPY 1
 int  csic_pipeline_set_mode(csic_pipeline *pipeline, int32_t mode);
 
+/* ---- PNG files in, PNG files out: the pipeline with the codec on worker threads ---------------------------------
+ * The batch counterpart of the reference's per-image  readImage -> DUT -> writeImage  flow (ImageProcessorModel.scala:14-52,
+ * ImageCompressorTopApp.scala:39-41,133-144) for `nfiles` PNGs that are all frames of `plan`: `decode_threads` workers
+ * decode straight into pinned frame slots and launch the fused kernel on the slot's stream (zero-copy over PCIe, as
+ * CSIC_PIPELINE_ZERO_COPY), `encode_threads` workers wait for a slot and write out_paths[i] (8-bit RGB, zlib `png_level`).
+ * <= 0 threads = the library's choice (up to 32 decoders / 16 encoders, never more than files or host cores); the slots
+ * between the two pools are bounded (workers + 2, at most 8 GiB of pinned memory).  final_width / final_height > 0 select
+ * what the reference's collector keeps when the dimensions do not divide by the factor -- the first final_width *
+ * final_height pixels of the output stream, final_width per row, missing pixels magenta (ImageCompressorTopApp.scala:44-45,
+ * 133-142); 0 = the plan's output size.  Every output file is byte for byte what csic_png_read_argb -> csic_pipeline_* ->
+ * csic_png_write_argb on one thread writes for the same input.  The parent directories of out_paths must exist.
+ * Synchronous; the first failure stops the batch and is returned (message: "file <i>: ...").  *stats may be NULL. */
+typedef struct csic_files_stats {
+    int64_t frames;                   /* files written                                                                   */
+    double  wall_s;                   /* first worker started -> last worker finished                                     */
+    double  decode_s, encode_s;       /* summed over the workers of each pool: seconds inside the PNG decoder / encoder   */
+    double  gpu_wait_s, slot_wait_s;  /* encoders waiting for the GPU; decoders waiting for a free slot                    */
+    int32_t decode_threads, encode_threads, slots, max_in_flight;
+    int64_t in_pixels, out_pixels;
+} csic_files_stats;
+int  csic_process_png_files(csic_plan *plan, const char *const *in_paths, const char *const *out_paths, int32_t nfiles,
+                            int32_t decode_threads, int32_t encode_threads, int32_t png_level,
+                            int32_t final_width, int32_t final_height, csic_files_stats *stats);
+
 /* ---- cycle-level model of the Decoupled pixel stream (host only) ---------------------------
  * What the reference's users simulate is not a function from frames to frames but hardware: modules that exchange one
  * pixel per ready/valid handshake (ImageCompressorTop.scala:33-38), and its tests check the handshake as well as the

@@ -447,6 +447,72 @@ def test_app_process_images_batch(csic, oracle, tmp_path):
         assert np.array_equal(load_png_rgb(outs[k]), want)
 
 
+@pytest.mark.parametrize("threads", [(1, 1), (3, 2), (None, None), (8, 1)])
+def test_process_images_thread_pools_write_the_same_bytes_as_the_serial_path(csic, oracle, tmp_path, threads):
+    """csic_process_png_files (decoder / encoder pools around pinned frame slots) against round 2's serial flow: every
+    output FILE is byte-identical, and the decoded pixels are the oracle's."""
+    from PIL import Image as PILImage
+    W, H, n = 160, 96, 23
+    PS = csic.ProcessingStep
+    ins, a_out, b_out, rgbs = [], [], [], []
+    for k in range(n):
+        rgb = oracle.argb_to_rgb(oracle.synth_frame(W * H, 77 * k + 1).reshape(H, W))
+        if k % 3 == 0:                                               # some smooth frames too (other filter choices in the encoder)
+            yy, xx = np.mgrid[0:H, 0:W]
+            rgb = np.stack([(xx + k) & 255, (yy * 2) & 255, (xx + yy) & 255], -1).astype(np.uint8)
+        p = tmp_path / f"in{k}.png"
+        PILImage.fromarray(rgb, "RGB").save(p)
+        ins.append(str(p)); rgbs.append(rgb)
+        a_out.append(str(tmp_path / "serial" / f"o{k}.png")); b_out.append(str(tmp_path / "pool" / "deep" / f"o{k}.png"))
+    args = (2, 0, 3, 3, 2, 4, PS.ChromaSubsampling, PS.SpatialSampling, PS.ColorQuantization)
+    assert csic.ImageCompressionApp.processImages(ins, a_out, *args, decodeThreads=0) is None
+    st = csic.ImageCompressionApp.processImages(ins, b_out, *args, decodeThreads=threads[0], encodeThreads=threads[1])
+    assert st["frames"] == n and st["in_pixels"] == n * W * H and st["out_pixels"] == n * (W // 4) * (H // 4)
+    assert 1 <= st["decode_threads"] <= n and 1 <= st["encode_threads"] <= n and 2 <= st["slots"] <= n + 1
+    if threads[0]:
+        assert st["decode_threads"] == threads[0] and st["encode_threads"] == threads[1]
+    for k in range(n):
+        assert open(a_out[k], "rb").read() == open(b_out[k], "rb").read(), k
+        want = oracle.argb_to_rgb(oracle.process(_oparams(oracle, W, H, 2, 0, (3, 3, 2), 4), oracle.rgb_to_argb(rgbs[k])))
+        assert np.array_equal(load_png_rgb(b_out[k]), want), k
+
+
+def test_process_images_pool_non_divisible_dimensions_and_errors(csic, oracle, tmp_path):
+    """Dimensions that do not divide by the factor: the collector keeps the first (W/f)*(H/f) pixels of the ceil-sized output
+    stream (ImageCompressorTopApp.scala:44-45,108-124) -- same bytes from both paths.  A file of another size, a missing file
+    and an unwritable output fail the batch with the file's index in the message."""
+    from PIL import Image as PILImage
+    W, H, n = 50, 30, 6
+    PS = csic.ProcessingStep
+    ins, a_out, b_out = [], [], []
+    for k in range(n):
+        rgb = oracle.argb_to_rgb(oracle.synth_frame(W * H, 5 * k).reshape(H, W))
+        p = tmp_path / f"in{k}.png"
+        PILImage.fromarray(rgb, "RGB").save(p)
+        ins.append(str(p)); a_out.append(str(tmp_path / "s" / f"o{k}.png")); b_out.append(str(tmp_path / "p" / f"o{k}.png"))
+    args = (2, 0, 8, 8, 8, 4, PS.SpatialSampling, PS.ColorQuantization, PS.ChromaSubsampling)
+    csic.ImageCompressionApp.processImages(ins, a_out, *args, decodeThreads=0)
+    csic.ImageCompressionApp.processImages(ins, b_out, *args, decodeThreads=2, encodeThreads=2)
+    for k in range(n):
+        assert open(a_out[k], "rb").read() == open(b_out[k], "rb").read(), k
+        assert load_png_rgb(b_out[k]).shape == (H // 4, W // 4, 3)
+    other = tmp_path / "other.png"
+    PILImage.fromarray(np.zeros((H, W + 2, 3), np.uint8), "RGB").save(other)
+    with pytest.raises(csic.IllegalArgumentException, match="other.png is 52x30"):
+        csic.ImageCompressionApp.processImages(ins[:2] + [str(other)], b_out[:3], *args, decodeThreads=2, encodeThreads=1)
+    with pytest.raises(csic.CsicIOError):
+        csic.ImageCompressionApp.processImages(ins[:2] + [str(tmp_path / "missing.png")], b_out[:3], *args, decodeThreads=2, encodeThreads=1)
+    N = csic._native
+    pl = csic.Plan(csic.make_c_params(W, H, 2, 0, 8, 8, 8, 4, (1, 2, 3)), 0)
+    pi = (C.c_char_p * 2)(ins[0].encode(), ins[1].encode())
+    po = (C.c_char_p * 2)(str(tmp_path / "p" / "ok.png").encode(), str(tmp_path / "no_such_dir" / "x.png").encode())
+    assert N.lib().csic_process_png_files(pl._h, pi, po, 2, 2, 2, 6, 0, 0, None) == N.EIO
+    assert b"file 1" in N.lib().csic_last_error()
+    assert N.lib().csic_process_png_files(pl._h, pi, po, 0, 1, 1, 6, 0, 0, None) == N.EINVAL_SIZE
+    assert N.lib().csic_process_png_files(None, pi, po, 2, 1, 1, 6, 0, 0, None) == N.EINVAL_NULL
+    pl.close()
+
+
 @pytest.mark.parametrize("a,b", [(4, 4), (2, 2), (2, 0), (1, 1), (1, 0), (4, 0)])
 def test_f1_any_width_uses_dword_kernel(csic, oracle, a, b):
     """f = 1 with a width that is not a multiple of 4 (and therefore rows that are not 16-byte aligned):
