@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -49,6 +50,8 @@ struct Shared {
     std::mutex mu;
     std::condition_variable cv_free, cv_work;
     std::deque<int> free_slots;
+    int created = 0;                              // slots allocated so far (each by the decoder thread that first needed one:
+                                                  // pinning 35 MB takes ~10 ms, 50 slots one after the other were 0.5 s of a 1.2 s batch)
     std::deque<std::pair<int, int>> inflight;     // (slot, file index), oldest first
     int decoders_running = 0;
     std::atomic<int> next_file{0};
@@ -70,6 +73,20 @@ void fail(Shared &sh, int status, const std::string &msg)
     sh.cv_work.notify_all();
 }
 
+bool make_slot(Shared &sh, Slot &s)
+{
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&s.h_in), sh.in_px * 4, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_out), sh.out_px * 4, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fail(sh, e == hipErrorOutOfMemory ? CSIC_ENOMEM : CSIC_EHIP, std::string("frame-slot allocation failed: ") + hipGetErrorString(e));
+        return false;
+    }
+    return true;
+}
+
 void decoder(Shared &sh)
 {
     if (hipSetDevice(sh.device) != hipSuccess) { fail(sh, CSIC_EHIP, "decoder thread: cannot make the plan's device current"); }
@@ -81,10 +98,18 @@ void decoder(Shared &sh)
         {
             const auto w0 = Clock::now();
             std::unique_lock<std::mutex> lk(sh.mu);
-            sh.cv_free.wait(lk, [&] { return !sh.free_slots.empty() || sh.failed.load(); });
-            if (sh.failed.load()) break;
-            slot = sh.free_slots.front();
-            sh.free_slots.pop_front();
+            bool fresh = false;
+            if (sh.free_slots.empty() && sh.created < (int)sh.slots.size()) {
+                slot = sh.created++;                                               // mine to allocate, outside the lock
+                fresh = true;
+            } else {
+                sh.cv_free.wait(lk, [&] { return !sh.free_slots.empty() || sh.failed.load(); });
+                if (sh.failed.load()) break;
+                slot = sh.free_slots.front();
+                sh.free_slots.pop_front();
+            }
+            lk.unlock();
+            if (fresh && !make_slot(sh, sh.slots[slot])) break;
             t_wait += secs(w0, Clock::now());
         }
         Slot &s = sh.slots[slot];
@@ -160,6 +185,23 @@ void encoder(Shared &sh)
     sh.done_files += files;
 }
 
+// width and height from the first 33 bytes (signature + IHDR); anything odd is left to csic_png_info's full parse for its message
+bool peek_png_dims(const char *path, int32_t *w, int32_t *h)
+{
+    unsigned char b[33];
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return false;
+    const size_t got = std::fread(b, 1, sizeof b, fp);
+    std::fclose(fp);
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (got != sizeof b || std::memcmp(b, sig, 8) != 0 || std::memcmp(b + 12, "IHDR", 4) != 0) return false;
+    const uint32_t ww = ((uint32_t)b[16] << 24) | ((uint32_t)b[17] << 16) | ((uint32_t)b[18] << 8) | b[19];
+    const uint32_t hh = ((uint32_t)b[20] << 24) | ((uint32_t)b[21] << 16) | ((uint32_t)b[22] << 8) | b[23];
+    if (ww == 0 || hh == 0 || ww > 0x7FFFFFFFu || hh > 0x7FFFFFFFu) return false;
+    *w = (int32_t)ww; *h = (int32_t)hh;
+    return true;
+}
+
 } // namespace
 
 extern "C" {
@@ -186,8 +228,10 @@ int csic_process_png_files(csic_plan *plan, const char *const *in_paths, const c
     // the files must be frames of this plan: checked up front so that a wrong batch fails before any thread starts
     for (int i = 0; i < nfiles; ++i) {
         int32_t w = 0, h = 0;
-        const int st = csic_png_info(in_paths[i], &w, &h);
-        if (st != CSIC_OK) return st;
+        if (!peek_png_dims(in_paths[i], &w, &h)) {
+            const int st = csic_png_info(in_paths[i], &w, &h);
+            if (st != CSIC_OK) return st;
+        }
         if ((size_t)w * (size_t)h != sh.in_px || w != plan_width(plan))
             return set_error(CSIC_EINVAL_SIZE, "%s is %dx%d, the plan processes %dx%zu frames", in_paths[i], w, h, plan_width(plan),
                              sh.in_px / (size_t)plan_width(plan));
@@ -210,13 +254,6 @@ int csic_process_png_files(csic_plan *plan, const char *const *in_paths, const c
 
     CSIC_DEVICE_SCOPE(sh.device);
     try { sh.slots.resize(S); } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
-    hipError_t e = hipSuccess;
-    for (auto &s : sh.slots) {
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_in), sh.in_px * 4, hipHostMallocMapped);
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_out), sh.out_px * 4, hipHostMallocMapped);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
-    }
     auto release = [&] {
         for (auto &s : sh.slots) {
             if (s.stream) (void)hipStreamSynchronize(s.stream);
@@ -226,12 +263,7 @@ int csic_process_png_files(csic_plan *plan, const char *const *in_paths, const c
             if (s.h_out) (void)hipHostFree(s.h_out);
         }
     };
-    if (e != hipSuccess) {
-        release();
-        return set_error(e == hipErrorOutOfMemory ? CSIC_ENOMEM : CSIC_EHIP, "frame-slot allocation failed: %s", hipGetErrorString(e));
-    }
-    for (size_t k = 0; k < S; ++k) sh.free_slots.push_back((int)k);
-    sh.decoders_running = D;
+    sh.decoders_running = D;                      // (slots are created by the decoder threads, when first needed)
 
     const auto t0 = Clock::now();
     std::vector<std::thread> pool;
@@ -254,7 +286,7 @@ int csic_process_png_files(csic_plan *plan, const char *const *in_paths, const c
         stats->frames = sh.done_files;
         stats->wall_s = wall;
         stats->decode_s = sh.decode_s; stats->encode_s = sh.encode_s; stats->gpu_wait_s = sh.gpu_wait_s; stats->slot_wait_s = sh.slot_wait_s;
-        stats->decode_threads = D; stats->encode_threads = E; stats->slots = (int32_t)S; stats->max_in_flight = sh.max_inflight;
+        stats->decode_threads = D; stats->encode_threads = E; stats->slots = (int32_t)sh.created; stats->max_in_flight = sh.max_inflight;
         stats->in_pixels = (int64_t)sh.in_px * sh.done_files; stats->out_pixels = (int64_t)sh.final_px * sh.done_files;
     }
     if (sh.failed.load()) return set_error(sh.status, "%s", sh.message.c_str());

@@ -388,7 +388,7 @@ typedef struct csic_files_stats {
     double  wall_s;                   /* first worker started -> last worker finished                                     */
     double  decode_s, encode_s;       /* summed over the workers of each pool: seconds inside the PNG decoder / encoder   */
     double  gpu_wait_s, slot_wait_s;  /* encoders waiting for the GPU; decoders waiting for a free slot                    */
-    int32_t decode_threads, encode_threads, slots, max_in_flight;
+    int32_t decode_threads, encode_threads, slots, max_in_flight;   /* slots = pinned frame slots actually allocated */
     int64_t in_pixels, out_pixels;
 } csic_files_stats;
 int  csic_process_png_files(csic_plan *plan, const char *const *in_paths, const char *const *out_paths, int32_t nfiles,
