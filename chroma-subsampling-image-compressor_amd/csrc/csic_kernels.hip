@@ -349,6 +349,54 @@ __global__ void __launch_bounds__(256) k_dec(KArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_decflat: chroma before spatial with h <= F (the chroma stage is unobservable, no cross-lane hold), for rows that
+// k_dec cannot cut into whole blocks -- Wo % K != 0 (1000-wide frames at f = 4 / 8: Wo = 250 / 125) or a lane count with no
+// usable divisor (Wo = 1028: 257 lanes).  There k_dec puts its last chunk -- for narrow rows EVERY chunk -- on the
+// bounds-checked path, whose exec-mask regions and s_waitcnt vmcnt(0) before every store serialise the wave (1000x1000
+// f = 8: 64.8 % of the HBM roofline against 80.5 % for 1024x1024, with HBM traffic only 1.05x the algorithmic bytes:
+// profiles/r03_pmc_summary / pmc_traffic.json sq1000_csq, sq1024_csq).  Here the lanes cover the flat DECIMATED stream
+// instead: output index i -> (ro, co) = (i / Wo, i % Wo) by an exact multiply-shift (magic_div), K indices per lane spaced
+// by the block size, so every block but the frame's last runs the straight-line path and a wave stores 256 contiguous
+// bytes per instruction whatever the row width (row ends no longer split stores into partial lines: WRITE_SIZE was 1.29x
+// the output bytes for k_dec on these rows).
+// ------------------------------------------------------------------------------------------------
+template <int ROUND, int FMT, int F, int K, bool NT, bool CHECK>
+__device__ __forceinline__ void decflat_body(const KArgs &a, gin_t in, gout_t out, uint32_t i0, uint32_t T, uint32_t n)
+{
+    uint32_t px[K];
+    int64_t oo[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        // the frame's last block: clamp instead of branching so that the K loads still issue back to back
+        const uint32_t i = CHECK ? min(i0 + (uint32_t)k * T, n - 1) : i0 + (uint32_t)k * T;
+        const uint32_t ro = (uint32_t)(((uint64_t)i * a.mWo) >> a.kWo);          // i / Wo, exact for i < 2^31
+        const uint32_t co = i - ro * (uint32_t)a.Wo;
+        px[k] = ld1<NT>(in + (int64_t)(ro * F) * a.ip + co * F);
+        oo[k] = (int64_t)ro * a.op + co;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (!CHECK || i0 + (uint32_t)k * T < n) {
+            const ChromaTerm t = chroma_term<ROUND, FMT>(px[k], a.mcb, a.mcr);
+            st1<NT>(out + oo[k], finish<FMT>(px[k], a.my, t));
+        }
+    }
+}
+
+template <int ROUND, int FMT, int F, int K, bool NT>
+__global__ void __launch_bounds__(256) k_decflat(KArgs a)
+{
+    pin_args(a);
+    const uint32_t T = (uint32_t)a.bdx;
+    const uint32_t n = (uint32_t)a.Wo * (uint32_t)a.Ho;
+    const uint32_t b0 = blockIdx.x * (T * K);
+    const gin_t in = frame_in(a);
+    const gout_t out = frame_out(a);
+    if (b0 + T * K <= n) decflat_body<ROUND, FMT, F, K, NT, false>(a, in, out, b0 + threadIdx.x, T, n);
+    else                 decflat_body<ROUND, FMT, F, K, NT, true>(a, in, out, b0 + threadIdx.x, T, n);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_dec2v: factor 2, chroma before spatial, h <= 2, W % 8 == 0 -- 16-byte loads.
 //   VAR 1: one lane = 4 input pixels (one dwordx4 load)  -> 2 output pixels (one dwordx2 store),
 //          loads and stores both dense across lanes.
@@ -623,7 +671,7 @@ __global__ void __launch_bounds__(256) k_checksum(const uint32_t *src, int64_t n
 // ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
-enum Family { FAM_F1X4, FAM_DEC, FAM_DEC2V1, FAM_DEC2V2, FAM_GENERIC, FAM_AVG, FAM_AVG_GENERIC };
+enum Family { FAM_F1X4, FAM_DEC, FAM_DEC2V1, FAM_DEC2V2, FAM_GENERIC, FAM_AVG, FAM_AVG_GENERIC, FAM_DECFLAT };
 
 } // namespace csic
 
@@ -685,6 +733,39 @@ static KernelFn pick_dec(int f, int hold, bool srows)
     if (f == 2) return pick_dec_f<ROUND, FMT, 2, NT>(hold, srows);
     if (f == 4) return pick_dec_f<ROUND, FMT, 4, NT>(hold, srows);
     return pick_dec_f<ROUND, FMT, 8, NT>(hold, srows);
+}
+
+template <int ROUND, int FMT, bool NT>
+static KernelFn pick_decflat(int f)
+{
+    if (f == 2) return k_decflat<ROUND, FMT, 2, DEC_K, NT>;
+    if (f == 4) return k_decflat<ROUND, FMT, 4, DEC_K, NT>;
+    return k_decflat<ROUND, FMT, 8, DEC_K, NT>;
+}
+
+// Block width k_dec would take for `lanes_x` lanes per row in blocks of `tpb` threads (prepare_common): a width that divides
+// the row exactly when there is one between tpb / 2 and tpb lanes, else the power of two that leaves a partial chunk.
+static int dec_block_x(int lanes_x, int tpb, int hold)
+{
+    int bx = 1;
+    while (bx < lanes_x) bx <<= 1;
+    if (bx > tpb) bx = tpb;
+    if (lanes_x <= tpb) {
+        if (lanes_x % hold == 0) bx = lanes_x;
+    } else {
+        for (int m = (lanes_x + tpb - 1) / tpb; m <= lanes_x / (tpb / 2); ++m)
+            if (lanes_x % m == 0 && (lanes_x / m) % hold == 0) { bx = lanes_x / m; break; }
+    }
+    return bx;
+}
+
+// k_dec leaves part of every row on its bounds-checked path: the row is not a whole number of K-pixel lanes, or the lanes
+// are not a whole number of blocks
+static bool dec_ragged(const Geometry &g)
+{
+    if (g.Wo % DEC_K != 0) return true;
+    const int lanes_x = g.Wo / DEC_K;
+    return lanes_x % dec_block_x(lanes_x, 256, 1) != 0;
 }
 
 template <int ROUND, int FMT, int F, bool NT>
@@ -772,6 +853,14 @@ static void select_rf(csic_plan *pl)
             pl->units_per_row = g.Wo / (pl->variant == 1 ? 2 : 4);
             pl->k_per_lane = 1;
             snprintf(pl->name, sizeof pl->name, "k_dec2v<%s,%s,var%d,%s>", rn, fn, pl->variant, ntn);
+        } else if (g.f >= 2 && hold == 1 && !srows && pl->variant != 5 && dec_ragged(g)) {
+            // rows k_dec cannot cut into whole blocks: lanes over the flat decimated stream (variant 5 keeps k_dec for A/B)
+            pl->fam = FAM_DECFLAT;
+            pl->dec_hold = 1;
+            pl->fn = nt ? pick_decflat<ROUND, FMT, true>(g.f) : pick_decflat<ROUND, FMT, false>(g.f);
+            pl->units_per_row = g.Wo;
+            pl->k_per_lane = DEC_K;
+            snprintf(pl->name, sizeof pl->name, "k_decflat<%s,%s,f%d,K%d,%s>", rn, fn, g.f, DEC_K, ntn);
         } else {
             pl->fam = FAM_DEC;
             pl->dec_hold = hold;
@@ -873,12 +962,17 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
         // their last chunk on the bounds-checked path.  A block width that divides the row exactly keeps
         // every block on the straight-line path (4K f=2: 70 % -> 80 % of HBM peak).  The width only has to
         // be a multiple of the lane-hold distance so that a DPP hold group never straddles two rows.
-        if (lanes_x <= tpb) {
-            if (lanes_x % hold == 0) bx = lanes_x;
-        } else {
-            for (int m = (lanes_x + tpb - 1) / tpb; m <= lanes_x / (tpb / 2); ++m)
-                if (lanes_x % m == 0 && (lanes_x / m) % hold == 0) { bx = lanes_x / m; break; }
-        }
+        bx = dec_block_x(lanes_x, tpb, hold);
+    }
+    if (fam == FAM_DECFLAT) {
+        // lanes over the flat decimated stream: blocks of whole waves, K indices per lane spaced by the block size
+        const int T = forced ? tpb : 256;
+        const int64_t per_block = (int64_t)T * kpl, n = (int64_t)g.Wo * g.Ho;
+        d->block = dim3((unsigned)T, 1, 1);
+        a.bdx = T; a.bdy = 1; a.row_step = 1;
+        d->grid = dim3((unsigned)((n + per_block - 1) / per_block), 1, (unsigned)nframes);
+        d->fn = fn;
+        return CSIC_OK;
     }
     if (fam == FAM_F1X4 && !forced) {
         // One 16-byte load and store per lane: this kernel lives on the wave launch rate, so waves that exit at once (the idle

@@ -615,6 +615,77 @@ def test_block_geometry_rules(csic, oracle, W, H, f, orders):
                     assert np.array_equal(got[k], want[k]), (pl.kernel_name, W, H, a, b, f, order, k)
 
 
+# ---- k_decflat: rows k_dec cannot cut into whole blocks ------------------------------------------------------
+@pytest.mark.parametrize("W,H,f", [(1000, 1000, 8), (1000, 96, 4), (2056, 24, 2), (5, 3, 2), (13, 9, 4), (250, 30, 2), (1366, 48, 2),
+                                   (3, 1, 8), (1001, 7, 4)])
+def test_decflat_serves_ragged_rows(csic, oracle, W, H, f):
+    """Chroma before spatial with h <= f and a decimated width that is not a whole number of 4-pixel lanes (or of blocks): the
+    lanes cover the flat decimated stream (k_decflat).  Every chroma mode whose hold is unobservable, both roundings and
+    output formats, quantised, single frames, batches, pitched surfaces and frames in separate buffers (pointer table);
+    CSIC_TUNE_VARIANT 5 keeps k_dec for A/B and must give the same pixels."""
+    import torch
+    N = csic._native
+    n = 3
+    host_in = oracle.synth_frame(n * W * H, 7 * W + H)
+    modes = [(a, b) for (a, b) in ((4, 4), (2, 2), (2, 0), (1, 1), (1, 0)) if 4 // a <= f]
+    for (a, b) in modes:
+        for order in (CSQ, (3, 2, 1), (2, 3, 1)):
+            for rounding, fmt in ((0, 0), (1, 1)):
+                op = _oparams(oracle, W, H, a, b, (5, 4, 3), f, order, rounding, fmt)
+                want = [oracle.process(op, host_in[k * W * H:(k + 1) * W * H], form="closed") for k in range(n)]
+                with _plan(csic, W, H, a, b, (5, 4, 3), f, order, rounding, fmt) as pl:
+                    assert pl.kernel_name.startswith("k_decflat<"), (pl.kernel_name, W, H, a, b, f)
+                    assert np.array_equal(pl.process_host(host_in[:W * H]), want[0]), (pl.kernel_name, W, H, a, b, f, order)
+                    d_in = torch.from_numpy(host_in.view(np.int32)).cuda()
+                    got = pl.process_device(d_in, nframes=n).cpu().numpy().view(np.uint32)
+                    for k in range(n):
+                        assert np.array_equal(got[k], want[k]), (pl.kernel_name, W, H, a, b, f, order, k)
+                    pl.tune(N.TUNE_VARIANT, 5)
+                    assert pl.kernel_name.startswith("k_dec<")
+                    assert np.array_equal(pl.process_device(d_in, nframes=n).cpu().numpy().view(np.uint32)[1], want[1])
+                    pl.tune(N.TUNE_VARIANT, 0)
+                    assert pl.kernel_name.startswith("k_decflat<")
+    # pitched surfaces and a pointer table (CSIC_FRAME_GRAPH_FUSED), one mode
+    a, b, order = 2, 0, CSQ
+    op = _oparams(oracle, W, H, a, b, (8, 8, 8), f, order)
+    want = [oracle.process(op, host_in[k * W * H:(k + 1) * W * H], form="closed") for k in range(n)]
+    with _plan(csic, W, H, a, b, (8, 8, 8), f, order) as pl:
+        Wo, Ho = pl.out_width, pl.out_height
+        ip, opitch = W + 5, Wo + 3
+        surf = torch.zeros(n * H * ip, dtype=torch.int32, device="cuda:0")
+        surf.view(n * H, ip)[:, :W] = torch.from_numpy(host_in.view(np.int32).reshape(n * H, W)).cuda()
+        osurf = torch.full((n * Ho * opitch,), -1, dtype=torch.int32, device="cuda:0")
+        pl.process_device_pitched(surf, ip, osurf, opitch, nframes=n)
+        torch.cuda.synchronize()
+        o = osurf.view(n * Ho, opitch).cpu().numpy().view(np.uint32)
+        for k in range(n):
+            assert np.array_equal(o[k * Ho:(k + 1) * Ho, :Wo], want[k]), ("pitched", W, H, f, k)
+        assert (o[:, Wo:] == 0xFFFFFFFF).all()                              # the padding is never written
+        d_ins = [torch.from_numpy(host_in[k * W * H:(k + 1) * W * H].view(np.int32)).cuda() for k in range(n)]
+        d_outs = [torch.zeros(Wo * Ho, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+        for backend in ("fused", "direct", "hip"):
+            for t in d_outs:
+                t.zero_()
+            with csic.FrameGraph(pl, d_ins, d_outs, backend=backend) as g:
+                g.launch()
+                torch.cuda.synchronize()
+            for k in range(n):
+                assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(Ho, Wo), want[k]), (backend, W, H, f, k)
+
+
+def test_decflat_is_only_taken_where_k_dec_is_ragged(csic):
+    """Shapes that tile stay on k_dec (and its tuned block geometries); the hold / order classes k_decflat does not cover too."""
+    for (W, H, a, b, f, op, prefix) in [
+            (8192, 8192, 2, 0, 2, CSQ, "k_dec<"), (3840, 2160, 2, 0, 4, CSQ, "k_dec<"), (1024, 1024, 2, 0, 8, CSQ, "k_dec<"),
+            (1000, 1000, 2, 0, 2, CSQ, "k_dec<"),                       # Wo = 500: 125 lanes = one exact block row
+            (1000, 1000, 2, 0, 8, CSQ, "k_decflat<"), (1000, 1000, 1, 1, 2, CSQ, "k_dec<"),     # 4:1:1 at f = 2 holds across lanes
+            (1000, 1000, 2, 0, 8, (1, 3, 2), "k_generic<"),             # spatial before chroma, f does not divide W
+            (1000, 96, 2, 0, 4, (1, 2, 3), "k_dec<"),                   # spatial before chroma fast path (its own row logic)
+            (2056, 64, 4, 4, 2, CSQ, "k_decflat<")]:                    # 257 lanes: no divisor between 128 and 256
+        with _plan(csic, W, H, a, b, (8, 8, 8), f, op) as pl:
+            assert pl.kernel_name.startswith(prefix), (pl.kernel_name, W, H, a, b, f, op)
+
+
 # ---- launch-geometry edges ---------------------------------------------------------------------------------
 def test_batched_launch_every_kernel_family(csic, oracle):
     """Several frames per launch (frame index on grid z) for every kernel family, including narrow frames
