@@ -47,6 +47,10 @@ struct KArgs {
     uint32_t *const *out_tab;           //   null = frames lie back to back behind `in` / `out`
 };
 
+// The direct-dispatch engine copies sizeof(KArgs) bytes into raw kernarg memory (csic_graph.hip): every translation unit must
+// see this one layout -- there is exactly one copy of this header (tests/test_bench_contract.py checks that, too).
+static_assert(sizeof(KArgs) == 152 && alignof(KArgs) == 8, "KArgs layout changed: check the kernarg blocks built in csic_graph.hip");
+
 using KernelFn = void (*)(KArgs);
 
 // One fully resolved launch of the fused kernel: what hipLaunchKernel / hipGraphAddKernelNode need.

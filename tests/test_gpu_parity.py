@@ -616,7 +616,7 @@ def test_block_geometry_rules(csic, oracle, W, H, f, orders):
 
 
 # ---- k_decflat: rows k_dec cannot cut into whole blocks ------------------------------------------------------
-@pytest.mark.parametrize("W,H,f", [(1000, 1000, 8), (1000, 96, 4), (2056, 24, 2), (5, 3, 2), (13, 9, 4), (250, 30, 2), (1366, 48, 2),
+@pytest.mark.parametrize("W,H,f", [(1000, 1000, 8), (1000, 96, 4), (2056, 24, 2), (5, 3, 2), (21, 9, 4), (250, 30, 2), (1366, 48, 2),
                                    (3, 1, 8), (1001, 7, 4)])
 def test_decflat_serves_ragged_rows(csic, oracle, W, H, f):
     """Chroma before spatial with h <= f and a decimated width that is not a whole number of 4-pixel lanes (or of blocks): the
