@@ -31,7 +31,8 @@ bench)
   $B --config cfg3 --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config sq1000 --order scq --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config sq1024 --order scq --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
-  $B --config sq1000 --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1      # k_dec on the SAME 1000x1000 frames (chroma before spatial)
+  $B --config sq1000 --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1      # the SAME 1000x1000 frames, chroma before spatial: k_decflat
+  $B --config sq1000 --frames-per-step 1024 --variant 5 >> "$J" 2>> "$OUT/bench.err" || exit 1   # ... and k_dec on them (A/B, CSIC_TUNE_VARIANT 5)
   wc -l "$J"
   ;;
 profile)
