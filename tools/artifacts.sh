@@ -44,6 +44,7 @@ profile)
 profile_rows)
   # the weakest shapes: 1000-pixel rows in both order classes next to the aligned 1024 shape
   bash tools/profile.sh $TAG sq1000_csq --config sq1000 --frames-per-step 1024 > "$OUT/profile_sq1000_csq.log" 2>&1 || { tail -5 "$OUT/profile_sq1000_csq.log"; exit 1; }
+  bash tools/profile.sh $TAG sq1000_csq_kdec --config sq1000 --frames-per-step 1024 --variant 5 > "$OUT/profile_sq1000_csq_kdec.log" 2>&1 || { tail -5 "$OUT/profile_sq1000_csq_kdec.log"; exit 1; }
   bash tools/profile.sh $TAG sq1000_scq --config sq1000 --order scq --frames-per-step 1024 > "$OUT/profile_sq1000_scq.log" 2>&1 || { tail -5 "$OUT/profile_sq1000_scq.log"; exit 1; }
   bash tools/profile.sh $TAG sq1024_scq --config sq1024 --order scq --frames-per-step 1024 > "$OUT/profile_sq1024_scq.log" 2>&1 || { tail -5 "$OUT/profile_sq1024_scq.log"; exit 1; }
   bash tools/profile.sh $TAG sq1024_csq --config sq1024 --frames-per-step 1024 > "$OUT/profile_sq1024_csq.log" 2>&1 || { tail -5 "$OUT/profile_sq1024_csq.log"; exit 1; }

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_bench_all_configs.jsonl")
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_bench_all_configs.jsonl")
     print("| # | workload (`config.workload`) | launch (`config.launch`) | kernel | Mpx/s (input) | µs / step (launches per step) | µs / launch (HIP events) | "
           "algorithmic GB/s | % HBM roofline | same launches through the direct engine: stream-ordered µs / launch (%) · host-ordered µs / launch (%) |")
     print("|---|---|---|---|---|---|---|---|---|---|")
