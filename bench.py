@@ -211,6 +211,24 @@ class Comm:
         return int(round(self.allsum(1.0 if guard.err is not None else 0.0)))
 
 
+def run_with_deadline(fn, seconds, on_timeout):
+    """Runs fn() on the calling thread; if it has not returned after `seconds`, on_timeout() is called ON A WATCHDOG THREAD
+    (fn may be stuck inside a native call that never comes back -- a transport that wedged -- so the caller's thread cannot be
+    relied on any more; on_timeout is expected to finish the process's business and os._exit).  Returns fn()'s result."""
+    done = threading.Event()
+
+    def watch():
+        if not done.wait(seconds):
+            on_timeout()
+
+    t = threading.Thread(target=watch, name="deadline", daemon=True)
+    t.start()
+    try:
+        return fn()
+    finally:
+        done.set()
+
+
 _INJECT = os.environ.get("CSIC_BENCH_INJECT_FAIL", "")       # test hook: "rank=1,issue=direct,phase=timed" (tests/test_bench_protocol.py)
 
 
@@ -619,6 +637,11 @@ def main(argv=None):
                          "the library.  They take HBM bandwidth from every issue mode alike; what the table in profiles/ compares is how "
                          "each launch backend holds up beside them (`busy_streams` in the line says whether they outlasted the timed region)")
     ap.add_argument("--no-halo", action="store_true", help="N>1: skip the `halo_exchange` side measurement")
+    ap.add_argument("--halo-timeout", type=float, default=60.0,
+                    help="N>1: seconds the `halo_exchange` side measurement may take.  It is the one step that uses point-to-point "
+                         "transport (RCCL send/recv), which no one-GPU box can rehearse: if it wedges, every rank gives up on it after "
+                         "this long, rank 0 prints the line with the object marked unavailable, and the processes exit 0 -- the "
+                         "headline is already measured by then")
     ap.add_argument("--no-sustained", action="store_true",
                     help="N=1: skip the `sustained` leg (the headline launches replayed in bursts for as long as the CPU baseline "
                          "runs on its host thread)")
@@ -857,6 +880,7 @@ def main(argv=None):
         return res
 
     sides = {}
+    want_halo = False
 
     def safe_side(key, scaling, how):
         """A side measurement must never cost the headline line: side() turns every local failure into an all-reduced verdict;
@@ -882,11 +906,7 @@ def main(argv=None):
         if can_graph and not args.no_side and issue in ("direct", "hip"):
             other_issue = "hip" if issue == "direct" else "direct"
             safe_side("hip_streams" if other_issue == "hip" else "direct_dispatch", headline_mode, other_issue)
-        if not args.no_halo and args.config not in AVG_CONFIGS:
-            try:
-                sides["halo_exchange"] = halo_exchange(args, csic, torch, dist, comm, dev, dev_index, world, rank)
-            except Exception as exc:                               # noqa: BLE001
-                sides["halo_exchange"] = {"unavailable": f"{type(exc).__name__}: {exc}"}
+        want_halo = not args.no_halo and args.config not in AVG_CONFIGS
     elif args.stripe_of > 1 and can_graph and not args.no_side:
         other_issue = "hip" if issue == "direct" else "direct"
         safe_side("hip_streams" if other_issue == "hip" else "direct_dispatch", headline_mode, other_issue)
@@ -894,7 +914,12 @@ def main(argv=None):
     elif args.direct and can_graph and issue != "direct":
         safe_side("direct_dispatch", headline_mode, "direct")
 
-    if rank == 0:
+
+    def emit():
+        """Rank 0 prints THE line (everything measured so far; called exactly once -- at the end, or by the watchdog of the
+        halo exchange)."""
+        if rank != 0:
+            return
         traffic, traffic_note = load_traffic(args.config, head["kernel"], world)
         if args.frames_per_step > 0 or args.order != "csq" or args.per_frame_graph or args.block_threads or args.variant >= 0 or args.no_vector \
                 or args.pitch_pad:
@@ -961,6 +986,24 @@ def main(argv=None):
         if cpu_res is not None:
             line["cpu_baseline"] = cpu_res
         print(json.dumps(line), flush=True)
+
+    if want_halo:
+        # The one step that needs point-to-point transport.  Everything else is measured; if this wedges (a send/recv that never
+        # pairs up), the watchdog prints the line without it and ends the process -- it cannot cost the headline.
+        def give_up():
+            sides["halo_exchange"] = {"unavailable": f"did not finish within {args.halo_timeout:.0f} s (transport wedged?); every rank gave up on it"}
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+
+        def run_halo():
+            try:
+                return halo_exchange(args, csic, torch, dist, comm, dev, dev_index, world, rank)
+            except Exception as exc:                               # noqa: BLE001
+                return {"unavailable": f"{type(exc).__name__}: {exc}"}
+
+        sides["halo_exchange"] = run_with_deadline(run_halo, args.halo_timeout, give_up)
+    emit()
 
     if pg:
         dist.destroy_process_group()

@@ -144,3 +144,23 @@ def test_a_failing_side_measurement_is_a_verdict_not_a_hang(tmp_path):
 def test_three_ranks(tmp_path):
     recs = _run(tmp_path, "rank=2,issue=direct,phase=timed", world=3)
     assert [r["issue"] for r in recs] == ["hip"] * 3
+
+
+def test_run_with_deadline_calls_the_watchdog_only_when_the_work_is_stuck():
+    """bench.py guards the one step that needs point-to-point transport (the halo exchange) with a deadline: a call that comes
+    back in time returns its result and the watchdog stays silent; one that does not triggers on_timeout on another thread."""
+    import threading
+    bench = _load_bench()
+    fired = []
+    assert bench.run_with_deadline(lambda: 42, 5.0, lambda: fired.append("late")) == 42
+    time.sleep(0.05)
+    assert fired == []
+    gate = threading.Event()
+
+    def stuck():
+        gate.wait(10.0)                                            # "a native call that never returns", released by the watchdog here
+        return "released"
+
+    t0 = time.perf_counter()
+    assert bench.run_with_deadline(stuck, 0.2, lambda: (fired.append("late"), gate.set())) == "released"
+    assert fired == ["late"] and 0.15 < time.perf_counter() - t0 < 5.0
