@@ -351,7 +351,8 @@ __global__ void __launch_bounds__(256) k_dec(KArgs a)
 // ------------------------------------------------------------------------------------------------
 // k_decflat: chroma before spatial with h <= F (the chroma stage is unobservable, no cross-lane hold), for rows that
 // k_dec cannot cut into whole blocks -- Wo % K != 0 (1000-wide frames at f = 4 / 8: Wo = 250 / 125) or a lane count with no
-// usable divisor (Wo = 1028: 257 lanes).  There k_dec puts its last chunk -- for narrow rows EVERY chunk -- on the
+// usable divisor (Wo = 1028: 257 lanes) --, for rows of a few partly filled waves (125, 90, 44, 160 lanes) and, since it is
+// level or slightly ahead there too, for rows of whole waves: everything but k_dec's one-wave-block shapes (dec_prefers_flat).  There k_dec puts its last chunk -- for narrow rows EVERY chunk -- on the
 // bounds-checked path, whose exec-mask regions and s_waitcnt vmcnt(0) before every store serialise the wave (1000x1000
 // f = 8: 64.8 % of the HBM roofline against 80.5 % for 1024x1024, with HBM traffic only 1.05x the algorithmic bytes:
 // profiles/r03_pmc_summary / pmc_traffic.json sq1000_csq, sq1024_csq).  Here the lanes cover the flat DECIMATED stream
@@ -759,13 +760,30 @@ static int dec_block_x(int lanes_x, int tpb, int hold)
     return bx;
 }
 
-// k_dec leaves part of every row on its bounds-checked path: the row is not a whole number of K-pixel lanes, or the lanes
-// are not a whole number of blocks
-static bool dec_ragged(const Geometry &g)
+// One-wave blocks for narrow rows (a row needs at most two waves and tiles into them): see prepare_common.
+static bool dec_one_wave_blocks(int lanes_x, int f, int hold)
+{
+    if (lanes_x < 16 || lanes_x > 128) return false;
+    bool tiles = (f >= 4 && lanes_x < 64) || (lanes_x & (lanes_x - 1)) == 0;       // 16, 32, 64, 128; any < 64 for f >= 4
+    for (int w = 64; !tiles && w >= 48; --w) tiles = lanes_x % w == 0 && w % hold == 0;
+    return tiles && (lanes_x >= 64 || lanes_x % hold == 0);
+}
+
+// Should a chroma-before-spatial, hold-free plan cover the flat decimated stream (k_decflat) instead of rows (k_dec)?
+// Measured over 22 shapes (tools/probe_flat.py, profiles/r03_probe_flat.log; batched launches, k_dec | flat):
+//  * rows k_dec cannot cut into whole blocks -- not a whole number of K-pixel lanes, or lanes without a usable divisor: every
+//    block of k_dec runs its bounds-checked path (1000x1000 f = 4 / 8: 66 / 63 | 73 / 71 %; 1366x768 f = 2: 68 | 79 %);
+//  * rows of a few partly filled waves that straddle two rows at odd offsets (1000x1000 f = 2: 70 | 78 %, 720x480 f = 2:
+//    70 | 78 %, 352x288 f = 2: 70 | 81 %, 1280x720 f = 2: 78.5 | 81.5 %);
+//  * rows of whole waves: level or slightly ahead (8192x8192 f = 2 / 4 / 8: 79.8 | 82.6, 76.3 | 76.9, 74.3 | 77.0 %; 3840x2160
+//    f = 4: 75.3 | 76.7 %; 1080p / 4K f = 2: 79.6 | 80.4 %), and on the headline -- ONE 8192x8192 frame per launch -- four
+//    interleaved repeats give 32.09 | 31.85 us = 78.4 | 79.0 % (profiles/r03_headline_flat_ab.jsonl);
+//  * the one exception: shapes that take k_dec's one-wave blocks (512x512 f = 2: 77 | 65-73 %; 1024x1024 f = 8: 79 | 70-78 %;
+//    640x480 f = 4 and 1920x1080 f = 4 level) stay with k_dec.
+static bool dec_prefers_flat(const Geometry &g)
 {
     if (g.Wo % DEC_K != 0) return true;
-    const int lanes_x = g.Wo / DEC_K;
-    return lanes_x % dec_block_x(lanes_x, 256, 1) != 0;
+    return !dec_one_wave_blocks(g.Wo / DEC_K, g.f, 1);
 }
 
 template <int ROUND, int FMT, int F, bool NT>
@@ -853,8 +871,9 @@ static void select_rf(csic_plan *pl)
             pl->units_per_row = g.Wo / (pl->variant == 1 ? 2 : 4);
             pl->k_per_lane = 1;
             snprintf(pl->name, sizeof pl->name, "k_dec2v<%s,%s,var%d,%s>", rn, fn, pl->variant, ntn);
-        } else if (g.f >= 2 && hold == 1 && !srows && pl->variant != 5 && dec_ragged(g)) {
-            // rows k_dec cannot cut into whole blocks: lanes over the flat decimated stream (variant 5 keeps k_dec for A/B)
+        } else if (g.f >= 2 && hold == 1 && !srows && pl->variant != 5 && (pl->variant == 6 || dec_prefers_flat(g))) {
+            // rows k_dec cannot cut into whole blocks or whole waves: lanes over the flat decimated stream (variant 5 keeps k_dec,
+            // variant 6 takes k_decflat wherever it applies: A/B)
             pl->fam = FAM_DECFLAT;
             pl->dec_hold = 1;
             pl->fn = nt ? pick_decflat<ROUND, FMT, true>(g.f) : pick_decflat<ROUND, FMT, false>(g.f);
@@ -950,9 +969,7 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
         // lanes) lose (70.8 -> 63.4) and keep the default, as do rows of fewer than 16 lanes (128x128 f=4/8: -1 %).
         // With f >= 4, rows of fewer than 64 lanes fit one wave whatever their width (640x480 f=4, 40 lanes: 74.1 -> 77.7 %;
         // 352x288 f=4 s>c: 62.0 -> 72.4 %); at f = 2 that loses (352x288, 44 lanes: 70.5 -> 59.3 %) and only powers of two qualify.
-        bool tiles = (g.f >= 4 && lanes_x < 64) || (lanes_x & (lanes_x - 1)) == 0;       // 16, 32, 64, 128; any < 64 for f >= 4
-        for (int w = 64; !tiles && w >= 48; --w) tiles = lanes_x % w == 0 && w % hold == 0;
-        if (tiles && (lanes_x >= 64 || lanes_x % hold == 0)) tpb = 64;
+        if (dec_one_wave_blocks(lanes_x, g.f, hold)) tpb = 64;
     }
     int bx = pow2_ceil(lanes_x);
     if (bx > tpb) bx = tpb;
@@ -966,7 +983,11 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
     }
     if (fam == FAM_DECFLAT) {
         // lanes over the flat decimated stream: blocks of whole waves, K indices per lane spaced by the block size
-        const int T = forced ? tpb : 256;
+        // Two-wave blocks at f = 2 (1000x1000 77.8 -> 78.6 %, 1366x768 77.1 -> 79.0, 352x288 80.5 -> 81.8, 8192x8192 80.0 -> 82.6)
+        // and for long rows at f = 4 / 8 (3840x2160 f = 4: 74.7 -> 76.7 %, 8192x8192 f = 8: 75.9 -> 77.0); four-wave blocks for
+        // short rows at f = 4 / 8 (1000x1000 f = 4: 72.3 % against 69.4 / 68.4 % with 128 / 64 threads; 1920x1080 f = 8: 75.7
+        // against 75.2 / 71.1).                                                      profiles/r03_probe_flat.log
+        const int T = forced ? tpb : ((g.f == 2 || g.Wo >= 512) ? 128 : 256);
         const int64_t per_block = (int64_t)T * kpl, n = (int64_t)g.Wo * g.Ho;
         d->block = dim3((unsigned)T, 1, 1);
         a.bdx = T; a.bdy = 1; a.row_step = 1;

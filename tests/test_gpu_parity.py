@@ -617,7 +617,7 @@ def test_block_geometry_rules(csic, oracle, W, H, f, orders):
 
 # ---- k_decflat: rows k_dec cannot cut into whole blocks ------------------------------------------------------
 @pytest.mark.parametrize("W,H,f", [(1000, 1000, 8), (1000, 96, 4), (2056, 24, 2), (5, 3, 2), (21, 9, 4), (250, 30, 2), (1366, 48, 2),
-                                   (3, 1, 8), (1001, 7, 4)])
+                                   (3, 1, 8), (1001, 7, 4), (1000, 64, 2), (720, 48, 2), (352, 40, 2), (1280, 24, 2)])
 def test_decflat_serves_ragged_rows(csic, oracle, W, H, f):
     """Chroma before spatial with h <= f and a decimated width that is not a whole number of 4-pixel lanes (or of blocks): the
     lanes cover the flat decimated stream (k_decflat).  Every chroma mode whose hold is unobservable, both roundings and
@@ -673,11 +673,15 @@ def test_decflat_serves_ragged_rows(csic, oracle, W, H, f):
                 assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(Ho, Wo), want[k]), (backend, W, H, f, k)
 
 
-def test_decflat_is_only_taken_where_k_dec_is_ragged(csic):
-    """Shapes that tile stay on k_dec (and its tuned block geometries); the hold / order classes k_decflat does not cover too."""
+def test_decflat_is_only_taken_where_it_wins(csic):
+    """One-wave-block shapes stay on k_dec, as do the hold / order classes k_decflat does not cover; everything else with chroma
+    before spatial and h <= f goes flat (profiles/r03_probe_flat.log)."""
     for (W, H, a, b, f, op, prefix) in [
-            (8192, 8192, 2, 0, 2, CSQ, "k_dec<"), (3840, 2160, 2, 0, 4, CSQ, "k_dec<"), (1024, 1024, 2, 0, 8, CSQ, "k_dec<"),
-            (1000, 1000, 2, 0, 2, CSQ, "k_dec<"),                       # Wo = 500: 125 lanes = one exact block row
+            (8192, 8192, 2, 0, 2, CSQ, "k_decflat<"), (3840, 2160, 2, 0, 4, CSQ, "k_decflat<"), (1024, 1024, 2, 0, 8, CSQ, "k_dec<"),
+            (1000, 1000, 2, 0, 2, CSQ, "k_decflat<"),                   # Wo = 500: 125 lanes, two waves that straddle rows
+            (720, 480, 2, 0, 2, CSQ, "k_decflat<"), (352, 288, 2, 0, 2, CSQ, "k_decflat<"), (1280, 720, 2, 0, 2, CSQ, "k_decflat<"),
+            (1920, 1080, 2, 0, 2, CSQ, "k_decflat<"), (512, 512, 2, 0, 2, CSQ, "k_dec<"), (640, 480, 2, 0, 4, CSQ, "k_dec<"),
+            (1920, 1080, 2, 0, 4, CSQ, "k_dec<"),
             (1000, 1000, 2, 0, 8, CSQ, "k_decflat<"), (1000, 1000, 1, 1, 2, CSQ, "k_dec<"),     # 4:1:1 at f = 2 holds across lanes
             (1000, 1000, 2, 0, 8, (1, 3, 2), "k_generic<"),             # spatial before chroma, f does not divide W
             (1000, 96, 2, 0, 4, (1, 2, 3), "k_dec<"),                   # spatial before chroma fast path (its own row logic)
