@@ -20,7 +20,6 @@ case "$STAGE" in
 bench)
   J=$OUT/bench_all_configs.jsonl; : > "$J"
   python bench.py --cpu-budget 5 --direct --one-launch >> "$J" 2> "$OUT/bench.err" || exit 1
-  python bench.py --no-cpu-baseline --variant 5 >> "$J" 2>> "$OUT/bench.err" || exit 1        # the headline frames through k_dec (round 2's kernel; A/B)
   for c in cfg5 8k_444_f1 8k_420_f1 avg_8k_420_sf2 avg_4k_420_sf4 cfg2 cfg3; do $B --config $c >> "$J" 2>> "$OUT/bench.err" || exit 1; done
   BN="python bench.py --no-cpu-baseline"
   $BN --config cfg5 --per-frame-graph --issue hip --graph-branches 1 --steps 1000 --warmup 200 >> "$J" 2>> "$OUT/bench.err" || exit 1
@@ -34,6 +33,8 @@ bench)
   $B --config sq1024 --order scq --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config sq1000 --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1      # the SAME 1000x1000 frames, chroma before spatial: k_decflat
   $B --config sq1000 --frames-per-step 1024 --variant 5 >> "$J" 2>> "$OUT/bench.err" || exit 1   # ... and k_dec on them (A/B, CSIC_TUNE_VARIANT 5)
+  python bench.py --no-cpu-baseline --variant 5 >> "$J" 2>> "$OUT/bench.err" || exit 1        # the headline frames through k_dec (round 2's kernel; A/B)
+  $BN --config cfg5 --variant 5 >> "$J" 2>> "$OUT/bench.err" || exit 1                           # cfg 5, one batched launch, through k_dec (A/B)
   wc -l "$J"
   ;;
 profile)
