@@ -275,6 +275,47 @@ def test_app_cli_reproduces_app_golden(csic, tmp_path, manifest):
     assert np.array_equal(load_png_rgb(str(out)), load_png_rgb(os.path.join(GOLDEN, e["file"])))
 
 
+def test_app_default_invocation_and_its_collector_budget(csic, oracle, tmp_path, capsys):
+    """The reference app's own defaults (in128x128.png, 4:4:4, 8/8/8, sf = 8, spatial -> color -> chroma;
+    ImageCompressorTopApp.scala:164-173).  By default every pixel is written.  With `--collector-budget emulate` the cycle
+    model says how many pixels the reference's collector gets before its budget of Wo*Ho*40 + 10000 cycles runs out (:110) --
+    160 of 256 -- and the rest keeps the magenta fill (:133-141), with the reference's [WARN] line.  Pixel values come from the
+    GPU in both cases."""
+    src = tmp_path / "in128x128.png"
+    src.write_bytes(open(os.path.join(GOLDEN, "inputs", "in128.png"), "rb").read())
+    name = "in128x128_processed_chroma4-4-4_Y8Cb8Cr8_sf8_order-Pr-Pr-Pr.png"
+    assert csic.app.main(["--input", str(src), "--outdir", str(tmp_path / "full")]) == 0
+    assert csic.app.main(["--input", str(src), "--outdir", str(tmp_path / "emu"), "--collector-budget", "emulate"]) == 0
+    assert "[WARN] Output collection timed out. Collected 160 out of 256 pixels." in capsys.readouterr().out
+    full, emu = load_png_rgb(str(tmp_path / "full" / name)), load_png_rgb(str(tmp_path / "emu" / name))
+    assert full.shape == emu.shape == (16, 16, 3)
+    rgb_in = load_png_rgb(str(src))
+    want = oracle.argb_to_rgb(oracle.process(_oparams(oracle, 128, 128, 4, 4, (8, 8, 8), 8, (1, 2, 3)), oracle.rgb_to_argb(rgb_in)))
+    assert np.array_equal(full, want)
+    assert np.array_equal(emu.reshape(-1, 3)[:160], want.reshape(-1, 3)[:160])
+    assert (emu.reshape(-1, 3)[160:] == (255, 0, 255)).all()
+
+
+@pytest.mark.parametrize("op", list(itertools.permutations((1, 2, 3))))
+def test_gpu_stream_equals_the_cycle_models_stream(csic, oracle, op):
+    """The PixelYCbCrBundle stream the GPU path produces (processYCbCr) is, pixel for pixel, what the cycle-level model of the
+    generated hardware emits on io.out -- for every op order, directly (not only through the oracle)."""
+    from csic_amd import stream as S
+    rng = np.random.default_rng(100 + op[0] * 9 + op[1])
+    for _ in range(6):
+        f = int(rng.choice([1, 2, 4, 8]))
+        a, b = [(4, 4), (2, 2), (2, 0), (1, 1), (1, 0)][int(rng.integers(0, 5))]
+        W, H = int(rng.integers(1, 70)), int(rng.integers(1, 40))
+        bits = tuple(int(x) for x in rng.integers(1, 9, 3))
+        frame = oracle.synth_frame(W * H, int(rng.integers(0, 1 << 30)))
+        top = csic.ImageCompressorTop(W, H, a, b, *bits, f, *[csic.ProcessingStep(o) for o in op])
+        got = top.processYCbCr(frame.reshape(H, W)).reshape(-1) & 0xFFFFFF
+        top.close()
+        with S.ImageCompressorTop(W, H, a, b, *bits, f, *op) as dut:
+            want, _ = dut.run(frame, out_ready_pattern=[1, 1, 0, 1])
+        assert np.array_equal(got, want), (W, H, a, b, bits, f, op)
+
+
 def test_image_processor_integration_flow(csic, input_images, manifest):
     """SpatialDownsamplerSpec.scala:155-230: in16x16 -> ImageProcessorParams(w,h,2,2,0) -> ImageProcessor
     -> 8x8; pixels pinned by APP_OUTPUT/spatial_downsampler_integration_420_sf2.png."""
