@@ -361,30 +361,47 @@ __global__ void __launch_bounds__(256) k_dec(KArgs a)
 // bytes per instruction whatever the row width (row ends no longer split stores into partial lines: WRITE_SIZE was 1.29x
 // the output bytes for k_dec on these rows).
 // ------------------------------------------------------------------------------------------------
-template <int ROUND, int FMT, int F, int K, bool NT, bool CHECK>
+// HOLD / SROWS as in k_dec.  The in-row hold stays a DPP inside an aligned quad of FLAT indices: a block starts at a multiple of
+// 4, and with HOLD | Wo a hold group never straddles two rows.  SROWS (spatial before chroma, 4:x:0): on an odd chroma row --
+// (ro / F) odd -- every pixel replays the last sample of the chroma row above; lanes of one wave may sit in different rows
+// here, so the held pixel is a per-lane load whose address is SELECTED (own pixel on even rows: a cache hit), not branched on.
+template <int ROUND, int FMT, int F, int HOLD, bool SROWS, int K, bool NT, bool CHECK>
 __device__ __forceinline__ void decflat_body(const KArgs &a, gin_t in, gout_t out, uint32_t i0, uint32_t T, uint32_t n)
 {
-    uint32_t px[K];
+    uint32_t px[K], hp[K];
     int64_t oo[K];
+    bool odd[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         // the frame's last block: clamp instead of branching so that the K loads still issue back to back
         const uint32_t i = CHECK ? min(i0 + (uint32_t)k * T, n - 1) : i0 + (uint32_t)k * T;
         const uint32_t ro = (uint32_t)(((uint64_t)i * a.mWo) >> a.kWo);          // i / Wo, exact for i < 2^31
         const uint32_t co = i - ro * (uint32_t)a.Wo;
-        px[k] = ld1<NT>(in + (int64_t)(ro * F) * a.ip + co * F);
+        const int64_t yoff = (int64_t)(ro * F) * a.ip + co * F;
+        px[k] = ld1<NT>(in + yoff);
         oo[k] = (int64_t)ro * a.op + co;
+        if (SROWS) {
+            const int r = (int)(ro >> a.sc_shift);                                // chroma row = ro / F
+            odd[k] = (r & a.vmask) != 0;
+            const int srow = ((r - 1) << a.sc_shift) + a.bc_row_off;             // decimated row of the held sample
+            const int64_t hoff = (int64_t)(srow * F) * a.ip + a.bc_col_in;
+            hp[k] = ld1<false>(in + (odd[k] ? hoff : yoff));
+        }
     }
+    uint32_t cpx[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) cpx[k] = hold_in_quad<HOLD>(px[k]);              // all lanes; a source lane <= its reader
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (!CHECK || i0 + (uint32_t)k * T < n) {
-            const ChromaTerm t = chroma_term<ROUND, FMT>(px[k], a.mcb, a.mcr);
+            const uint32_t c = (SROWS && odd[k]) ? hp[k] : cpx[k];
+            const ChromaTerm t = chroma_term<ROUND, FMT>(c, a.mcb, a.mcr);
             st1<NT>(out + oo[k], finish<FMT>(px[k], a.my, t));
         }
     }
 }
 
-template <int ROUND, int FMT, int F, int K, bool NT>
+template <int ROUND, int FMT, int F, int HOLD, bool SROWS, int K, bool NT>
 __global__ void __launch_bounds__(256) k_decflat(KArgs a)
 {
     pin_args(a);
@@ -393,8 +410,8 @@ __global__ void __launch_bounds__(256) k_decflat(KArgs a)
     const uint32_t b0 = blockIdx.x * (T * K);
     const gin_t in = frame_in(a);
     const gout_t out = frame_out(a);
-    if (b0 + T * K <= n) decflat_body<ROUND, FMT, F, K, NT, false>(a, in, out, b0 + threadIdx.x, T, n);
-    else                 decflat_body<ROUND, FMT, F, K, NT, true>(a, in, out, b0 + threadIdx.x, T, n);
+    if (b0 + T * K <= n) decflat_body<ROUND, FMT, F, HOLD, SROWS, K, NT, false>(a, in, out, b0 + threadIdx.x, T, n);
+    else                 decflat_body<ROUND, FMT, F, HOLD, SROWS, K, NT, true>(a, in, out, b0 + threadIdx.x, T, n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -736,12 +753,25 @@ static KernelFn pick_dec(int f, int hold, bool srows)
     return pick_dec_f<ROUND, FMT, 8, NT>(hold, srows);
 }
 
-template <int ROUND, int FMT, bool NT>
-static KernelFn pick_decflat(int f)
+template <int ROUND, int FMT, int F, bool NT>
+static KernelFn pick_decflat_f(int hold, bool srows)
 {
-    if (f == 2) return k_decflat<ROUND, FMT, 2, DEC_K, NT>;
-    if (f == 4) return k_decflat<ROUND, FMT, 4, DEC_K, NT>;
-    return k_decflat<ROUND, FMT, 8, DEC_K, NT>;
+    if (srows) {
+        if (hold == 1) return k_decflat<ROUND, FMT, F, 1, true, DEC_K, NT>;
+        if (hold == 2) return k_decflat<ROUND, FMT, F, 2, true, DEC_K, NT>;
+        return k_decflat<ROUND, FMT, F, 4, true, DEC_K, NT>;
+    }
+    if (hold == 1) return k_decflat<ROUND, FMT, F, 1, false, DEC_K, NT>;
+    if (hold == 2) return k_decflat<ROUND, FMT, F, 2, false, DEC_K, NT>;
+    return k_decflat<ROUND, FMT, F, 4, false, DEC_K, NT>;
+}
+
+template <int ROUND, int FMT, bool NT>
+static KernelFn pick_decflat(int f, int hold, bool srows)
+{
+    if (f == 2) return pick_decflat_f<ROUND, FMT, 2, NT>(hold, srows);
+    if (f == 4) return pick_decflat_f<ROUND, FMT, 4, NT>(hold, srows);
+    return pick_decflat_f<ROUND, FMT, 8, NT>(hold, srows);
 }
 
 // Block width k_dec would take for `lanes_x` lanes per row in blocks of `tpb` threads (prepare_common): a width that divides
@@ -780,10 +810,10 @@ static bool dec_one_wave_blocks(int lanes_x, int f, int hold)
 //    interleaved repeats give 32.09 | 31.85 us = 78.4 | 79.0 % (profiles/r03_headline_flat_ab.jsonl);
 //  * the one exception: shapes that take k_dec's one-wave blocks (512x512 f = 2: 77 | 65-73 %; 1024x1024 f = 8: 79 | 70-78 %;
 //    640x480 f = 4 and 1920x1080 f = 4 level) stay with k_dec.
-static bool dec_prefers_flat(const Geometry &g)
+static bool dec_prefers_flat(const Geometry &g, int hold)
 {
     if (g.Wo % DEC_K != 0) return true;
-    return !dec_one_wave_blocks(g.Wo / DEC_K, g.f, 1);
+    return !dec_one_wave_blocks(g.Wo / DEC_K, g.f, hold);
 }
 
 template <int ROUND, int FMT, int F, bool NT>
@@ -871,15 +901,20 @@ static void select_rf(csic_plan *pl)
             pl->units_per_row = g.Wo / (pl->variant == 1 ? 2 : 4);
             pl->k_per_lane = 1;
             snprintf(pl->name, sizeof pl->name, "k_dec2v<%s,%s,var%d,%s>", rn, fn, pl->variant, ntn);
-        } else if (g.f >= 2 && hold == 1 && !srows && pl->variant != 5 && (pl->variant == 6 || dec_prefers_flat(g))) {
-            // rows k_dec cannot cut into whole blocks or whole waves: lanes over the flat decimated stream (variant 5 keeps k_dec,
-            // variant 6 takes k_decflat wherever it applies: A/B)
+        } else if (g.f >= 2 && g.Wo % hold == 0 && pl->variant != 5 && (pl->variant == 6 || dec_prefers_flat(g, hold))) {
+            // lanes over the flat decimated stream (variant 5 keeps k_dec, variant 6 takes k_decflat wherever it applies: A/B);
+            // a hold group must not straddle two rows: hold | Wo (spatial before chroma has that from dec_fast_ok)
+            const bool sr = srows && g.v == 2;
             pl->fam = FAM_DECFLAT;
-            pl->dec_hold = 1;
-            pl->fn = nt ? pick_decflat<ROUND, FMT, true>(g.f) : pick_decflat<ROUND, FMT, false>(g.f);
+            pl->dec_hold = hold;
+            pl->fn = nt ? pick_decflat<ROUND, FMT, true>(g.f, hold, sr) : pick_decflat<ROUND, FMT, false>(g.f, hold, sr);
             pl->units_per_row = g.Wo;
             pl->k_per_lane = DEC_K;
-            snprintf(pl->name, sizeof pl->name, "k_decflat<%s,%s,f%d,K%d,%s>", rn, fn, g.f, DEC_K, ntn);
+            if (hold == 1 && !srows)
+                snprintf(pl->name, sizeof pl->name, "k_decflat<%s,%s,f%d,K%d,%s>", rn, fn, g.f, DEC_K, ntn);
+            else
+                snprintf(pl->name, sizeof pl->name, "k_decflat<%s,%s,f%d,hold%d,%s,K%d,%s>", rn, fn, g.f, hold,
+                         srows ? (g.v == 2 ? "s>c,v2" : "s>c") : "c>s", DEC_K, ntn);
         } else {
             pl->fam = FAM_DEC;
             pl->dec_hold = hold;

@@ -714,6 +714,37 @@ def test_decflat_serves_ragged_rows(csic, oracle, W, H, f):
                 assert np.array_equal(d_outs[k].cpu().numpy().view(np.uint32).reshape(Ho, Wo), want[k]), (backend, W, H, f, k)
 
 
+@pytest.mark.parametrize("W,H,f", [(1000, 96, 2), (1000, 128, 4), (1000, 64, 8), (2056, 32, 2), (500, 72, 2), (24, 16, 2), (40, 64, 8), (8192, 32, 2)])
+def test_decflat_with_hold_and_spatial_before_chroma(csic, oracle, W, H, f):
+    """k_decflat's other template branches, forced with CSIC_TUNE_VARIANT 6 wherever they apply: spatial before chroma (the chroma
+    counters run on the decimated stream modulo the FULL width: in-row hold as a DPP on flat indices, 4:x:0 odd chroma rows
+    replaying the last sample of the row above through a selected per-lane address) and chroma before spatial with a hold
+    across lanes (4:1:1 at f = 2).  Against the oracle's STREAMING form, and against k_dec (variant 5) on the same frames."""
+    import torch
+    N = csic._native
+    n = 3
+    host_in = oracle.synth_frame(n * W * H, 11 * W + f)
+    d_in = torch.from_numpy(host_in.view(np.int32)).cuda()
+    seen = set()
+    for (a, b) in ((4, 4), (2, 2), (2, 0), (1, 1), (1, 0)):
+        for order in (CSQ, (1, 3, 2), (1, 2, 3), (2, 1, 3)):
+            for rounding, fmt in ((0, 0), (1, 1)):
+                with _plan(csic, W, H, a, b, (6, 5, 4), f, order, rounding, fmt) as pl:
+                    pl.tune(N.TUNE_VARIANT, 6)
+                    if not pl.kernel_name.startswith("k_decflat<"):
+                        continue                                     # k_generic shapes (f does not divide W, h does not divide Wo)
+                    seen.add(pl.kernel_name.split(",K4")[0].split("<")[1].split(",", 2)[2])
+                    op = _oparams(oracle, W, H, a, b, (6, 5, 4), f, order, rounding, fmt)
+                    want = [oracle.process(op, host_in[k * W * H:(k + 1) * W * H], form="stream") for k in range(n)]
+                    got = pl.process_device(d_in, nframes=n).cpu().numpy().view(np.uint32)
+                    for k in range(n):
+                        assert np.array_equal(got[k], want[k]), (pl.kernel_name, W, H, a, b, f, order, k)
+                    pl.tune(N.TUNE_VARIANT, 5)
+                    assert not pl.kernel_name.startswith("k_decflat<")
+                    assert np.array_equal(pl.process_device(d_in, nframes=n).cpu().numpy().view(np.uint32)[2], want[2]), pl.kernel_name
+    assert any("s>c" in x for x in seen) or W % f != 0, seen
+
+
 def test_decflat_is_only_taken_where_it_wins(csic):
     """One-wave-block shapes stay on k_dec, as do the hold / order classes k_decflat does not cover; everything else with chroma
     before spatial and h <= f goes flat (profiles/r03_probe_flat.log)."""

@@ -14,9 +14,18 @@ import csic_amd as csic  # noqa: E402
 N = csic._native
 shapes = [(1000, 1000, 2), (1000, 1000, 4), (1000, 1000, 8), (1920, 1080, 2), (1920, 1080, 4), (1920, 1080, 8), (3840, 2160, 2), (3840, 2160, 4),
           (1280, 720, 2), (1280, 720, 4), (1366, 768, 2), (2560, 1440, 4), (8192, 8192, 2), (8192, 8192, 4), (8192, 8192, 8), (720, 480, 2), (500, 500, 2), (512, 512, 2), (1024, 1024, 8), (640, 480, 4), (352, 288, 2), (8192, 1024, 2)]
+MODES = {"csq": (2, 0, (3, 1, 2)), "scq420": (2, 0, (1, 3, 2)), "scq422": (2, 2, (1, 3, 2)), "scq444": (4, 4, (1, 3, 2)), "csq411": (1, 1, (3, 1, 2))}
+mode = sys.argv[1] if len(sys.argv) > 1 else "csq"
+a_, b_, op_ = MODES[mode]
+print(f"mode {mode}: 4:{a_}:{b_}, op {op_}", flush=True)
 for (W, H, f) in shapes:
-    cp = csic.make_c_params(W, H, 2, 0, 8, 8, 8, f, (3, 1, 2))
+    cp = csic.make_c_params(W, H, a_, b_, 8, 8, 8, f, op_)
     pl = csic.Plan(cp, 0)
+    pl.tune(N.TUNE_VARIANT, 6)
+    if not pl.kernel_name.startswith("k_decflat"):
+        print(f"{W}x{H} f={f}: no flat kernel for this shape ({pl.kernel_name})", flush=True)
+        pl.close()
+        continue
     alg = pl.algorithmic_bytes
     nfr = max(1, min(4096, (768 << 20) // alg))
     ring = 3 if nfr * alg > (1 << 30) else 6
