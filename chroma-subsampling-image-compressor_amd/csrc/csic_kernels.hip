@@ -349,7 +349,8 @@ __global__ void __launch_bounds__(256) k_dec(KArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_decflat: chroma before spatial with h <= F (the chroma stage is unobservable, no cross-lane hold), for rows that
+// k_decflat: factor F in {2,4,8}, both order classes wherever k_dec's fast path applies (and HOLD | Wo) -- first written for
+// chroma before spatial with h <= F (the chroma stage is unobservable, no cross-lane hold) on rows that
 // k_dec cannot cut into whole blocks -- Wo % K != 0 (1000-wide frames at f = 4 / 8: Wo = 250 / 125) or a lane count with no
 // usable divisor (Wo = 1028: 257 lanes) --, for rows of a few partly filled waves (125, 90, 44, 160 lanes) and, since it is
 // level or slightly ahead there too, for rows of whole waves: everything but k_dec's one-wave-block shapes (dec_prefers_flat).  There k_dec puts its last chunk -- for narrow rows EVERY chunk -- on the
@@ -369,7 +370,7 @@ template <int ROUND, int FMT, int F, int HOLD, bool SROWS, int K, bool NT, bool 
 __device__ __forceinline__ void decflat_body(const KArgs &a, gin_t in, gout_t out, uint32_t i0, uint32_t T, uint32_t n)
 {
     uint32_t px[K], hp[K];
-    int64_t oo[K];
+    int64_t oo[K], ho[K];
     bool odd[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -384,8 +385,16 @@ __device__ __forceinline__ void decflat_body(const KArgs &a, gin_t in, gout_t ou
             const int r = (int)(ro >> a.sc_shift);                                // chroma row = ro / F
             odd[k] = (r & a.vmask) != 0;
             const int srow = ((r - 1) << a.sc_shift) + a.bc_row_off;             // decimated row of the held sample
-            const int64_t hoff = (int64_t)(srow * F) * a.ip + a.bc_col_in;
-            hp[k] = ld1<false>(in + (odd[k] ? hoff : yoff));
+            ho[k] = odd[k] ? (int64_t)(srow * F) * a.ip + a.bc_col_in : yoff;
+        }
+    }
+    if (SROWS) {
+        // the held pixels, only for waves that have a lane on an odd chroma row (a wave-uniform branch: chroma rows are F
+        // decimated rows tall, so most waves are all-even -- no second load at all -- or all-odd -- one address for the wave)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            hp[k] = 0;
+            if (__builtin_amdgcn_ballot_w64(odd[k]) != 0) hp[k] = ld1<false>(in + ho[k]);
         }
     }
     uint32_t cpx[K];
@@ -809,7 +818,11 @@ static bool dec_one_wave_blocks(int lanes_x, int f, int hold)
 //    f = 4: 75.3 | 76.7 %; 1080p / 4K f = 2: 79.6 | 80.4 %), and on the headline -- ONE 8192x8192 frame per launch -- four
 //    interleaved repeats give 32.09 | 31.85 us = 78.4 | 79.0 % (profiles/r03_headline_flat_ab.jsonl);
 //  * the one exception: shapes that take k_dec's one-wave blocks (512x512 f = 2: 77 | 65-73 %; 1024x1024 f = 8: 79 | 70-78 %;
-//    640x480 f = 4 and 1920x1080 f = 4 level) stay with k_dec.
+//    640x480 f = 4 and 1920x1080 f = 4 level) stay with k_dec;
+//  * the same picture with a lane hold and with spatial before chroma (profiles/r03_probe_flat_{csq411,scq444,scq422,scq420}.log;
+//    4:2:0 spatial before chroma: 1000x1000 f = 2: 60 | 78 %, 352x288 f = 2: 61 | 80 %, 8192x8192 f = 2 / 4 / 8: 79.4 | 82.6,
+//    77.0 | 77.8, 75.2 | 77.5 % -- once the held-pixel load of the odd chroma rows is skipped wave-uniformly; loaded
+//    unconditionally it cost 8192x8192 f = 8 twenty points).
 static bool dec_prefers_flat(const Geometry &g, int hold)
 {
     if (g.Wo % DEC_K != 0) return true;

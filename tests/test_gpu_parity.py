@@ -746,17 +746,19 @@ def test_decflat_with_hold_and_spatial_before_chroma(csic, oracle, W, H, f):
 
 
 def test_decflat_is_only_taken_where_it_wins(csic):
-    """One-wave-block shapes stay on k_dec, as do the hold / order classes k_decflat does not cover; everything else with chroma
-    before spatial and h <= f goes flat (profiles/r03_probe_flat.log)."""
+    """One-wave-block shapes stay on k_dec, as do holds that would straddle rows and everything k_generic serves; every other
+    f >= 2 plan goes flat, in both order classes (profiles/r03_probe_flat*.log)."""
     for (W, H, a, b, f, op, prefix) in [
             (8192, 8192, 2, 0, 2, CSQ, "k_decflat<"), (3840, 2160, 2, 0, 4, CSQ, "k_decflat<"), (1024, 1024, 2, 0, 8, CSQ, "k_dec<"),
             (1000, 1000, 2, 0, 2, CSQ, "k_decflat<"),                   # Wo = 500: 125 lanes, two waves that straddle rows
             (720, 480, 2, 0, 2, CSQ, "k_decflat<"), (352, 288, 2, 0, 2, CSQ, "k_decflat<"), (1280, 720, 2, 0, 2, CSQ, "k_decflat<"),
             (1920, 1080, 2, 0, 2, CSQ, "k_decflat<"), (512, 512, 2, 0, 2, CSQ, "k_dec<"), (640, 480, 2, 0, 4, CSQ, "k_dec<"),
             (1920, 1080, 2, 0, 4, CSQ, "k_dec<"),
-            (1000, 1000, 2, 0, 8, CSQ, "k_decflat<"), (1000, 1000, 1, 1, 2, CSQ, "k_dec<"),     # 4:1:1 at f = 2 holds across lanes
+            (1000, 1000, 2, 0, 8, CSQ, "k_decflat<"), (1000, 1000, 1, 1, 2, CSQ, "k_decflat<"), # 4:1:1 at f = 2: a hold across lanes, Wo even
+            (1001, 64, 1, 1, 2, CSQ, "k_dec<"),                         # ... Wo = 501: a hold pair would straddle two rows
             (1000, 1000, 2, 0, 8, (1, 3, 2), "k_generic<"),             # spatial before chroma, f does not divide W
-            (1000, 96, 2, 0, 4, (1, 2, 3), "k_dec<"),                   # spatial before chroma fast path (its own row logic)
+            (1000, 96, 2, 0, 4, (1, 2, 3), "k_decflat<"),               # spatial before chroma, f | W and h | Wo: flat with the row logic
+            (1024, 1024, 2, 0, 8, (1, 3, 2), "k_dec<"), (8192, 512, 2, 0, 2, (1, 3, 2), "k_decflat<"),
             (2056, 64, 4, 4, 2, CSQ, "k_decflat<")]:                    # 257 lanes: no divisor between 128 and 256
         with _plan(csic, W, H, a, b, (8, 8, 8), f, op) as pl:
             assert pl.kernel_name.startswith(prefix), (pl.kernel_name, W, H, a, b, f, op)
