@@ -71,8 +71,9 @@ def test_random_shapes_vs_oracle(csic, oracle, seed):
             seen.add(pl.kernel_name.split("<")[0])
             got = pl.process_host(argb)
             assert np.array_equal(got, want), (pl.kernel_name, W, H, a, b, bits, f, op, rounding, fmt)
-            for variant in (1, 2, 4):                   # 16-byte-load f=2 variants; 4 = k_dec<f1> instead of k_f1x4
-                pl.tune(csic._native.TUNE_VARIANT, variant)
+            for variant in (1, 2, 4, 5, 6):             # 16-byte-load f=2 variants; 4 = k_dec<f1> instead of k_f1x4; 5 / 6 = never /
+                pl.tune(csic._native.TUNE_VARIANT, variant)   # always k_decflat where it applies
+                seen.add(pl.kernel_name.split("<")[0])
                 assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
             pl.tune(csic._native.TUNE_VARIANT, 0)
             pl.tune(csic._native.TUNE_NONTEMPORAL, 0)   # cached loads/stores instead of nt
@@ -83,7 +84,7 @@ def test_random_shapes_vs_oracle(csic, oracle, seed):
             pl.tune(csic._native.TUNE_FORCE_GENERIC, 1)
             assert pl.kernel_name.startswith("k_generic")
             assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
-    assert {"k_f1x4", "k_dec", "k_generic"} <= seen
+    assert {"k_f1x4", "k_dec", "k_decflat", "k_generic"} <= seen
 
 
 @pytest.mark.parametrize("a,b", [(4, 4), (2, 2), (2, 0), (1, 1), (1, 0), (4, 0)])
@@ -756,7 +757,7 @@ def test_decflat_is_only_taken_where_it_wins(csic):
             (1920, 1080, 2, 0, 4, CSQ, "k_dec<"),
             (1000, 1000, 2, 0, 8, CSQ, "k_decflat<"), (1000, 1000, 1, 1, 2, CSQ, "k_decflat<"), # 4:1:1 at f = 2: a hold across lanes, Wo even
             (1001, 64, 1, 1, 2, CSQ, "k_dec<"),                         # ... Wo = 501: a hold pair would straddle two rows
-            (1000, 1000, 2, 0, 8, (1, 3, 2), "k_generic<"),             # spatial before chroma, f does not divide W
+            (1000, 1000, 2, 0, 8, (1, 3, 2), "k_generic<"),             # spatial before chroma, h does not divide Wo = 125
             (1000, 96, 2, 0, 4, (1, 2, 3), "k_decflat<"),               # spatial before chroma, f | W and h | Wo: flat with the row logic
             (1024, 1024, 2, 0, 8, (1, 3, 2), "k_dec<"), (8192, 512, 2, 0, 2, (1, 3, 2), "k_decflat<"),
             (2056, 64, 4, 4, 2, CSQ, "k_decflat<")]:                    # 257 lanes: no divisor between 128 and 256
