@@ -548,7 +548,11 @@ def measure_headline(make_workload, first_issue, args, comm, allow_fallback=True
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser()
+    # Three kinds of switches.  The CONTRACT (what the driver passes): --gpus --steps --warmup.  What else is measured beside the
+    # headline in the same process ("side objects", never `value`).  And EXPERIMENT switches, each of which leaves the contract
+    # path: they exist so that every number quoted in DESIGN.md can be regenerated by tools/artifacts.sh with this one harness.
+    top = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap = top.add_argument_group("contract")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = 3200 launches' worth: 50 for cfg4, 3200 at one launch per step)")
     ap.add_argument("--warmup", type=int, default=-1, help="untimed warm-up steps (-1 = 512 launches' worth)")
@@ -559,6 +563,7 @@ def main(argv=None):
                     help="untimed conditioning before the W warm-up steps: replay the same launches for this long so "
                          "the GPU reaches its steady-state clocks (a 33 us step does not ramp DPM in 40 launches: "
                          "cfg4 measures 33.9 us/step cold vs 32.5 us/step conditioned)")
+    ap = top.add_argument_group("workload (default: BASELINE.json configs[3]; the others are parity / study configs)")
     ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--order", default="csq", choices=["csq", "scq"],
                     help="csq = chroma->spatial->quant (north-star order); scq = spatial->chroma->quant (the reference "
@@ -566,9 +571,11 @@ def main(argv=None):
     ap.add_argument("--frames-per-step", type=int, default=0,
                     help="override the config's frames per step: N contiguous frames in ONE batched launch "
                          "(csic_process_batch_device) -- puts the tiny cfg2/cfg3 kernels at a size where the roofline means something")
+    ap = top.add_argument_group("experiments: kernel A/B knobs")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (CSIC_TUNE_VARIANT); -1 = library default")
     ap.add_argument("--no-vector", action="store_true", help="CSIC_TUNE_NO_VECTOR: 4-byte-access kernels only (A/B)")
     ap.add_argument("--block-threads", type=int, default=0, choices=[0, 64, 128, 256], help="CSIC_TUNE_BLOCK_THREADS (A/B)")
+    ap = top.add_argument_group("N > 1 (one process per GPU under torch.distributed.run)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak", "both"],
                     help="N>1: strong (default; `value` = ONE frame of the config split N ways, the weak number is measured "
                          "afterwards and reported beside it), weak (`value` = one full frame per rank), both == strong")
@@ -586,6 +593,7 @@ def main(argv=None):
                     help="N=1: form the process group anyway (launch under torch.distributed.run --nproc-per-node 1) and run "
                          "the barriers and reductions through it -- with --backend nccl this brings up a real RCCL communicator "
                          "beside the launch engine on a one-GPU box")
+    ap = top.add_argument_group("how the launches are issued, and side objects")
     ap.add_argument("--per-frame-graph", action="store_true",
                     help="multi-frame configs (cfg5): replay a hipGraph of per-frame launches (what BASELINE.json's "
                          "cfg 5 literally names) instead of the single batched launch")
@@ -613,6 +621,7 @@ def main(argv=None):
                          "`rocprofv3 --stats` of the default command sees only the per-frame launches of the headline kernel)")
     ap.add_argument("--no-side", action="store_true",
                     help="N>1: skip the side measurement of the other issue mode (`hip_streams`)")
+    ap = top.add_argument_group("experiments: launch environment")
     ap.add_argument("--streams", type=int, default=1,
                     help="EXPERIMENT (default 1 = the contract): issue consecutive steps round-robin on this many HIP "
                          "streams so that one frame's ramp-up overlaps the previous frame's drain.  Per-kernel durations "
@@ -636,6 +645,7 @@ def main(argv=None):
                          "the whole timed region -- a host that decodes, converts or copies on its own streams while frames go through "
                          "the library.  They take HBM bandwidth from every issue mode alike; what the table in profiles/ compares is how "
                          "each launch backend holds up beside them (`busy_streams` in the line says whether they outlasted the timed region)")
+    ap = top.add_argument_group("side measurements")
     ap.add_argument("--no-halo", action="store_true", help="N>1: skip the `halo_exchange` side measurement")
     ap.add_argument("--halo-timeout", type=float, default=60.0,
                     help="N>1: seconds the `halo_exchange` side measurement may take.  It is the one step that uses point-to-point "
@@ -647,7 +657,7 @@ def main(argv=None):
                          "runs on its host thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
-    args = ap.parse_args(argv)
+    args = top.parse_args(argv)
     args.batch = args.batch_frames if args.batch_frames > 0 else \
         (DEFAULT_BATCH.get(args.config, 1) if args.frames_per_step <= 0 and not args.per_frame_graph else 1)
     if args.steps <= 0:
