@@ -662,6 +662,76 @@ __global__ void __launch_bounds__(256) k_generic(KArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_flatgen: the plans k_decflat's fast conditions exclude -- spatial before chroma where f does not divide W or h does not
+// divide Wo (the chroma counters run over the decimated stream modulo the FULL width, ImageCompressorTop.scala:52-58, so a hold
+// group starts at an arbitrary lane and may straddle two decimated rows) -- on the same mapping: lanes over the flat decimated
+// stream, K indices per lane.  k_generic fetches the chroma source of every pixel with a second gather (58-68 % of the HBM
+// roofline on 1000x1000); here the source of output j is output j - d's OWN pixel, d = (j mod W) mod h < 4, which the lane d
+// places to the left has just loaded: one ds_bpermute instead of a load.  Only the first d lanes of a wave (their source sits in
+// the previous wave) and the odd chroma rows of 4:x:0 (every pixel replays the last sample of the chroma row above) load a
+// second pixel, through a wave-uniform branch that most waves skip.  Run-time parameters like k_generic: one kernel per
+// (rounding, format).
+// ------------------------------------------------------------------------------------------------
+template <int ROUND, int FMT, int K, bool NT, bool CHECK>
+__device__ __forceinline__ void flatgen_body(const KArgs &a, gin_t in, gout_t out, uint32_t i0, uint32_t T, uint32_t n)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    uint32_t px[K], hp[K];
+    int64_t yo[K], oo[K], ho[K];
+    int dd[K];
+    bool need[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t j = CHECK ? min(i0 + (uint32_t)k * T, n - 1) : i0 + (uint32_t)k * T;
+        const uint32_t ro = (uint32_t)(((uint64_t)j * a.mWo) >> a.kWo);           // j / Wo, exact for j < 2^31
+        const uint32_t co = j - ro * (uint32_t)a.Wo;
+        yo[k] = (int64_t)(ro * (uint32_t)a.f) * a.ip + co * (uint32_t)a.f;
+        px[k] = ld1<NT>(in + yo[k]);
+        oo[k] = (int64_t)ro * a.op + co;
+        int r, d;
+        if (a.s_first) {                                                          // counters over the decimated stream, width W
+            r = (int)(((uint64_t)j * a.mW) >> a.kW);
+            d = ((int)j - r * a.W) & a.hmask;
+        } else {                                                                  // counters == image coordinates (rows ro * f are sample rows)
+            r = 0;
+            d = (int)((co * (uint32_t)a.f) & (uint32_t)a.hmask) >> a.sc_shift;
+        }
+        const bool odd = (r & a.vmask) != 0;
+        const int src = odd ? (r - 1) * a.W + a.last_sample_col : (int)j - d;    // flat index whose OWN pixel is the chroma source
+        const int sro = (int)(((uint64_t)(uint32_t)src * a.mWo) >> a.kWo), sco = src - sro * a.Wo;
+        ho[k] = (int64_t)(sro * a.f) * a.ip + sco * a.f;
+        dd[k] = odd ? 0 : d;
+        need[k] = odd || d > lane;                                                // not in a lane of this wave
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        hp[k] = 0;
+        if (__builtin_amdgcn_ballot_w64(need[k]) != 0) hp[k] = ld1<false>(in + (need[k] ? ho[k] : yo[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t nb = (uint32_t)__shfl((int)px[k], lane - dd[k], 64);       // all lanes take part
+        if (!CHECK || i0 + (uint32_t)k * T < n) {
+            const ChromaTerm t = chroma_term<ROUND, FMT>(need[k] ? hp[k] : nb, a.mcb, a.mcr);
+            st1<NT>(out + oo[k], finish<FMT>(px[k], a.my, t));
+        }
+    }
+}
+
+template <int ROUND, int FMT, int K, bool NT>
+__global__ void __launch_bounds__(256) k_flatgen(KArgs a)
+{
+    pin_args(a);
+    const uint32_t T = (uint32_t)a.bdx;
+    const uint32_t n = (uint32_t)a.Wo * (uint32_t)a.Ho;
+    const uint32_t b0 = blockIdx.x * (T * K);
+    const gin_t in = frame_in(a);
+    const gout_t out = frame_out(a);
+    if (b0 + T * K <= n) flatgen_body<ROUND, FMT, K, NT, false>(a, in, out, b0 + threadIdx.x, T, n);
+    else                 flatgen_body<ROUND, FMT, K, NT, true>(a, in, out, b0 + threadIdx.x, T, n);
+}
+
+// ------------------------------------------------------------------------------------------------
 // utilities: synthetic frames and checksum
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h)
@@ -938,6 +1008,15 @@ static void select_rf(csic_plan *pl)
             snprintf(pl->name, sizeof pl->name, "k_dec<%s,%s,f%d,hold%d,%s,K%d,%s>", rn, fn, g.f, hold,
                      g.f == 1 ? (g.v == 2 ? "v2" : "v1") : srows ? (g.v == 2 ? "s>c,v2" : "s>c") : "c>s", DEC_K, ntn);
         }
+    } else if (!pl->force_generic && !ycc_in && g.f >= 2 && pl->variant != 7) {
+        // what k_dec / k_decflat cannot take (spatial before chroma with f not dividing W or h not dividing Wo; tiny frames with a
+        // hold): the general flat kernel; variant 7 keeps the one-pixel-per-lane k_generic for A/B
+        pl->fam = FAM_DECFLAT;
+        pl->dec_hold = 1;
+        pl->fn = nt ? (KernelFn)k_flatgen<ROUND, FMT, DEC_K, true> : (KernelFn)k_flatgen<ROUND, FMT, DEC_K, false>;
+        pl->units_per_row = g.Wo;
+        pl->k_per_lane = DEC_K;
+        snprintf(pl->name, sizeof pl->name, "k_flatgen<%s,%s,K%d,%s>", rn, fn, DEC_K, ntn);
     } else {
         pl->fam = FAM_GENERIC;
         pl->fn = ycc_in ? (KernelFn)k_generic<ROUND, FMT, F_YCC> : (KernelFn)k_generic<ROUND, FMT, F_ARGB>;

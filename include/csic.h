@@ -173,7 +173,7 @@ const char *csic_plan_kernel_name(const csic_plan *plan);
 
 /* Tuning knobs for A/B measurements; a knob the selected kernel does not have is ignored.
  *   CSIC_TUNE_VARIANT : kernel-family specific variant index (0 = default; 1, 2 = the 16-byte f = 2 kernels, 4 = k_dec for
- *                       f = 1, 5 = k_dec instead of k_decflat on rows that do not tile into whole blocks / waves, 6 = k_decflat wherever it applies)
+ *                       f = 1, 5 = k_dec instead of k_decflat on rows that do not tile into whole blocks / waves, 6 = k_decflat wherever it applies, 7 = the one-pixel-per-lane k_generic instead of k_flatgen)
  *   CSIC_TUNE_FORCE_GENERIC : 1 = always use the one-thread-per-pixel generic kernel
  *   CSIC_TUNE_NONTEMPORAL   : 1 (default) = non-temporal loads/stores for the frame stream, 0 = cached
  *   CSIC_TUNE_NO_VECTOR     : 1 = never use the 16-byte-per-lane kernels

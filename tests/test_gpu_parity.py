@@ -746,6 +746,55 @@ def test_decflat_with_hold_and_spatial_before_chroma(csic, oracle, W, H, f):
     assert any("s>c" in x for x in seen) or W % f != 0, seen
 
 
+@pytest.mark.parametrize("W,H,f", [(1000, 40, 8), (1001, 33, 2), (30, 20, 4), (1366, 24, 4), (7, 5, 2), (130, 64, 8), (4099, 9, 2), (3, 3, 2),
+                                   (250, 17, 4), (66, 40, 8)])
+def test_flatgen_serves_what_the_fast_paths_exclude(csic, oracle, W, H, f):
+    """Spatial before chroma where f does not divide W or h does not divide Wo: the chroma counters run over the decimated
+    stream modulo the FULL width, so hold groups start at arbitrary lanes and straddle decimated rows.  k_flatgen takes the
+    chroma source from the lane d places to the left (ds_bpermute) and loads only what no lane of the wave holds; against the
+    oracle's STREAMING form and against k_generic (CSIC_TUNE_VARIANT 7) -- every chroma mode, the three spatial-first orders,
+    batches, pitched surfaces, frames in separate buffers."""
+    import torch
+    N = csic._native
+    n = 3
+    host_in = oracle.synth_frame(n * W * H, 3 * W + 5 * H + f)
+    d_in = torch.from_numpy(host_in.view(np.int32)).cuda()
+    took = 0
+    for (a, b) in ((4, 4), (2, 2), (2, 0), (1, 1), (1, 0)):
+        for order in ((1, 3, 2), (1, 2, 3), (2, 1, 3)):
+            for rounding, fmt in ((0, 0), (1, 1)):
+                with _plan(csic, W, H, a, b, (5, 6, 3), f, order, rounding, fmt) as pl:
+                    if not pl.kernel_name.startswith("k_flatgen<"):
+                        continue                                     # this mode has a fast path on this shape
+                    took += 1
+                    op = _oparams(oracle, W, H, a, b, (5, 6, 3), f, order, rounding, fmt)
+                    want = [oracle.process(op, host_in[k * W * H:(k + 1) * W * H], form="stream") for k in range(n)]
+                    assert np.array_equal(pl.process_host(host_in[:W * H]), want[0]), (W, H, a, b, f, order)
+                    got = pl.process_device(d_in, nframes=n).cpu().numpy().view(np.uint32)
+                    for k in range(n):
+                        assert np.array_equal(got[k], want[k]), (pl.kernel_name, W, H, a, b, f, order, k)
+                    Wo, Ho = pl.out_width, pl.out_height
+                    ip, opitch = W + 3, Wo + 2
+                    surf = torch.zeros(n * H * ip, dtype=torch.int32, device="cuda:0")
+                    surf.view(n * H, ip)[:, :W] = d_in.view(n * H, W)
+                    osurf = torch.full((n * Ho * opitch,), -1, dtype=torch.int32, device="cuda:0")
+                    pl.process_device_pitched(surf, ip, osurf, opitch, nframes=n)
+                    o = osurf.view(n * Ho, opitch).cpu().numpy().view(np.uint32)
+                    assert np.array_equal(o[Ho:2 * Ho, :Wo], want[1]) and (o[:, Wo:] == 0xFFFFFFFF).all(), ("pitched", W, H, a, b, f)
+                    if rounding == 0:
+                        d_ins = [d_in[k * W * H:(k + 1) * W * H] for k in range(n)]
+                        d_outs = [torch.zeros(Wo * Ho, dtype=torch.int32, device="cuda:0") for _ in range(n)]
+                        for backend in ("fused", "direct"):
+                            with csic.FrameGraph(pl, d_ins, d_outs, backend=backend) as g:
+                                g.launch()
+                                torch.cuda.synchronize()
+                            assert np.array_equal(d_outs[2].cpu().numpy().view(np.uint32).reshape(Ho, Wo), want[2]), (backend, W, H, a, b, f)
+                    pl.tune(N.TUNE_VARIANT, 7)
+                    assert pl.kernel_name.startswith("k_generic<")
+                    assert np.array_equal(pl.process_device(d_in, nframes=n).cpu().numpy().view(np.uint32)[1], want[1])
+    assert took > 0, "no mode of this shape reached k_flatgen"
+
+
 def test_decflat_is_only_taken_where_it_wins(csic):
     """One-wave-block shapes stay on k_dec, as do holds that would straddle rows and everything k_generic serves; every other
     f >= 2 plan goes flat, in both order classes (profiles/r03_probe_flat*.log)."""
@@ -757,7 +806,7 @@ def test_decflat_is_only_taken_where_it_wins(csic):
             (1920, 1080, 2, 0, 4, CSQ, "k_dec<"),
             (1000, 1000, 2, 0, 8, CSQ, "k_decflat<"), (1000, 1000, 1, 1, 2, CSQ, "k_decflat<"), # 4:1:1 at f = 2: a hold across lanes, Wo even
             (1001, 64, 1, 1, 2, CSQ, "k_dec<"),                         # ... Wo = 501: a hold pair would straddle two rows
-            (1000, 1000, 2, 0, 8, (1, 3, 2), "k_generic<"),             # spatial before chroma, h does not divide Wo = 125
+            (1000, 1000, 2, 0, 8, (1, 3, 2), "k_flatgen<"),             # spatial before chroma, h does not divide Wo = 125
             (1000, 96, 2, 0, 4, (1, 2, 3), "k_decflat<"),               # spatial before chroma, f | W and h | Wo: flat with the row logic
             (1024, 1024, 2, 0, 8, (1, 3, 2), "k_dec<"), (8192, 512, 2, 0, 2, (1, 3, 2), "k_decflat<"),
             (2056, 64, 4, 4, 2, CSQ, "k_decflat<")]:                    # 257 lanes: no divisor between 128 and 256

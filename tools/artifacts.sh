@@ -35,6 +35,7 @@ bench)
   $B --config sq1000 --frames-per-step 1024 --variant 5 >> "$J" 2>> "$OUT/bench.err" || exit 1   # ... and k_dec on them (A/B, CSIC_TUNE_VARIANT 5)
   python bench.py --no-cpu-baseline --variant 5 >> "$J" 2>> "$OUT/bench.err" || exit 1        # the headline frames through k_dec (round 2's kernel; A/B)
   $BN --config cfg5 --variant 5 >> "$J" 2>> "$OUT/bench.err" || exit 1                           # cfg 5, one batched launch, through k_dec (A/B)
+  $BN --config sq1000 --order scq --frames-per-step 1024 --variant 7 >> "$J" 2>> "$OUT/bench.err" || exit 1   # row 16's frames through k_generic (A/B)
   wc -l "$J"
   ;;
 profile)
@@ -47,6 +48,7 @@ profile_rows)
   # the weakest shapes: 1000-pixel rows in both order classes next to the aligned 1024 shape
   bash tools/profile.sh $TAG sq1000_csq --config sq1000 --frames-per-step 1024 > "$OUT/profile_sq1000_csq.log" 2>&1 || { tail -5 "$OUT/profile_sq1000_csq.log"; exit 1; }
   bash tools/profile.sh $TAG sq1000_csq_kdec --config sq1000 --frames-per-step 1024 --variant 5 > "$OUT/profile_sq1000_csq_kdec.log" 2>&1 || { tail -5 "$OUT/profile_sq1000_csq_kdec.log"; exit 1; }
+  bash tools/profile.sh $TAG sq1000_scq_kgeneric --config sq1000 --order scq --frames-per-step 1024 --variant 7 > "$OUT/profile_sq1000_scq_kgeneric.log" 2>&1 || { tail -5 "$OUT/profile_sq1000_scq_kgeneric.log"; exit 1; }
   bash tools/profile.sh $TAG sq1000_scq --config sq1000 --order scq --frames-per-step 1024 > "$OUT/profile_sq1000_scq.log" 2>&1 || { tail -5 "$OUT/profile_sq1000_scq.log"; exit 1; }
   bash tools/profile.sh $TAG sq1024_scq --config sq1024 --order scq --frames-per-step 1024 > "$OUT/profile_sq1024_scq.log" 2>&1 || { tail -5 "$OUT/profile_sq1024_scq.log"; exit 1; }
   bash tools/profile.sh $TAG sq1024_csq --config sq1024 --frames-per-step 1024 > "$OUT/profile_sq1024_csq.log" 2>&1 || { tail -5 "$OUT/profile_sq1024_csq.log"; exit 1; }
