@@ -40,7 +40,7 @@ def main():
     mean = lambda xs: sum(xs) / len(xs)
     kd = mean([r["roofline"]["kernel_ms_avg"] for r in hd if "k_dec<" in r["config"]["kernel"]]) * 1e3
     kf = mean([r["roofline"]["kernel_ms_avg"] for r in hd if "k_decflat<" in r["config"]["kernel"]]) * 1e3
-    a20, a21 = rows[19], rows[20]                  # the A/B lines at the end of the file
+    a20, a21, a22 = rows[19], rows[20], rows[21]   # the A/B lines at the end of the file
     r = lambda k: t[k]["traffic_over_algorithmic"]
     sec3 = f"""## 3. Numbers measured by the build (round 3, one MI355X, device-resident frames, FLOOR_HW)
 
@@ -59,7 +59,9 @@ under `profiles/r01_*`, `profiles/r02_*`.
 
 {table}
 The headline kernel changed in round 3: chroma before spatial with h ≤ f now runs `k_decflat` (lanes over the flat decimated
-stream, DESIGN.md §4) except on shapes that take `k_dec`'s one-wave blocks. Rows 20–21 are the A/B lines, the same frames through
+stream, DESIGN.md §4) except on shapes that take `k_dec`'s one-wave blocks, and what no fast path covers runs `k_flatgen` instead of
+`k_generic` (row 16 against row 22, `CSIC_TUNE_VARIANT` 7: {100 * rows[15]['roofline']['frac']:.1f} % against {100 * a22['roofline']['frac']:.1f} %; 1366×768 at sf 2 / 4: 43 / 45 → 70 / 75 %,
+`profiles/r03_probe_flatgen.log`). Rows 20–21 are A/B lines too, the same frames through
 round 2's `k_dec` (`CSIC_TUNE_VARIANT` 5): headline {100 * a20['roofline']['frac']:.1f} % against row 1's {100 * rows[0]['roofline']['frac']:.1f} %, cfg 5
 {100 * a21['roofline']['frac']:.1f} % against row 2's {100 * rows[1]['roofline']['frac']:.1f} %; four interleaved repeats of the headline:
 {kd:.2f} µs (`k_dec`) against {kf:.2f} µs (`k_decflat`) per launch (`profiles/r03_headline_flat_ab.jsonl`).
@@ -76,8 +78,8 @@ frames. How the backends hold up beside other busy HIP streams of the host proce
 streams copying 64 MiB blocks back to back the fused launch keeps {bs[('fused', 2)]:.1f} % — its share of the bandwidth — while
 stream-ordered direct dispatch falls to {bs[('direct', 2)]:.1f} % and hipGraph chains to {bs[('hip', 2)]:.1f} %: the per-frame-launch
 backends are for hosts whose other streams are quiet while frames go through). Rows 16–19 are the 1000×1000 frames whose rows
-are not a whole number of 128-byte lines: `k_generic` (spatial before chroma with `f ∤ W`, row 16) against `k_dec` on the nearest
-aligned shape (row 17), and the same frames with chroma before spatial through `k_decflat` (row 18) and through `k_dec` (row 19,
+are not a whole number of 128-byte lines: `k_flatgen` (spatial before chroma where `h ∤ Wo`, row 16; `k_generic` on the same frames: row 22)
+against `k_dec` on the nearest aligned shape (row 17), and the same frames with chroma before spatial through `k_decflat` (row 18) and through `k_dec` (row 19,
 `CSIC_TUNE_VARIANT` 5: every block on its bounds-checked path). 2/4/8-GPU numbers are filled by the driver's scaling run
 (`SCALE_rNN.json`): at N > 1 `value` is the strong split of ONE 8192×8192 frame (pre-recorded launches on the launch stream:
 hipGraph chains at N = 2, direct dispatch at N = 4 and 8; a mode that fails on any rank is replaced on every rank,
@@ -97,8 +99,8 @@ HBM traffic from PMC counters (FETCH_SIZE ×2, WRITE_SIZE ×1, separate passes, 
 cfg 4 {t['cfg4']['hbm_bytes_per_launch']:,} B per launch = {r('cfg4')} × the algorithmic 201 326 592 B; cfg 5 {r('cfg5')} × (round 2's `k_dec`: 1.009 ×);
 8192² 4:4:4 sf 1 {r('8k_444_f1')} ×; 8192² 4:2:0 sf 1 {r('8k_420_f1')} ×. The unaligned rows (1024 frames of 1000×1000 per launch, sf 8):
 `k_dec` chroma→spatial {r('sq1000_csq_kdec')} × (reads {t['sq1000_csq_kdec']['hbm_read_bytes_per_launch'] / 512e6:.3f} ×, writes {t['sq1000_csq_kdec']['hbm_write_bytes_per_launch'] / 64e6:.3f} × — row ends split its stores into partial lines),
-`k_decflat` on the same frames {r('sq1000_csq')} × (writes {t['sq1000_csq']['hbm_write_bytes_per_launch'] / 64e6:.3f} ×: what 62 500-byte output frames cost in 32-byte sectors), `k_generic`
-spatial→chroma {r('sq1000_scq')} ×, against {r('sq1024_csq')} × / {r('sq1024_scq')} × for 1024×1024. Wasted traffic explains 3–5 points of the gap to the aligned shape
+`k_decflat` on the same frames {r('sq1000_csq')} × (writes {t['sq1000_csq']['hbm_write_bytes_per_launch'] / 64e6:.3f} ×: what 62 500-byte output frames cost in 32-byte sectors), spatial→chroma
+`k_flatgen` {r('sq1000_scq')} × and `k_generic` {r('sq1000_scq_kgeneric')} ×, against {r('sq1024_csq')} × / {r('sq1024_scq')} × for 1024×1024. Wasted traffic explains 3–5 points of the gap to the aligned shape
 at most; the rest was control flow (fixed by `k_decflat`) and is request efficiency (DESIGN.md §4).
 CPU C (Scala/JVM path): no JVM on the GPU box (`java` not found) — not measured, not substituted; the model to time is written
 (`chroma-subsampling-image-compressor_amd/jvm/scala/jpeg/SoftwareModel.scala`).
