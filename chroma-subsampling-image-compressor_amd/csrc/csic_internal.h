@@ -3,6 +3,7 @@
 #include "csic.h"
 
 #include <cstdarg>
+#include <cstddef>
 #include <cstdint>
 
 namespace csic {
@@ -27,5 +28,11 @@ int  derive_geometry(const csic_params *p, Geometry *g);   // validates first
 // (Error term e = m*d - 2^k < d <= 2^ceil(log2 d), and n * e < 2^31 * 2^ceil(log2 d) = 2^k.)  Host side, csic_host.cpp;
 // checked against the hardware divide over edge cases and random pairs in tests/cpp/host_sanitize.cpp.
 void magic_div(uint32_t d, uint32_t *m, uint32_t *k);
+
+// csic_inflate.cpp: what the PNG reader needs of zlib, faster.  zlib_decode_exact: 0 if in[0, in_len) is a well-formed zlib
+// stream of exactly out_len bytes with the right check value (1 corrupt, 2 truncated, 3 longer, 4 shorter than out_len).
+int      zlib_decode_exact(const unsigned char *in, size_t in_len, unsigned char *out, size_t out_len);
+uint32_t crc32_update(uint32_t crc, const unsigned char *p, size_t n);      // crc32_update(0, ..) starts a CRC, as zlib's crc32
+uint32_t adler32_update(uint32_t adler, const unsigned char *p, size_t n);  // adler32_update(1, ..) starts a sum, as zlib's adler32
 
 } // namespace csic

@@ -1,4 +1,5 @@
-// csic_png.cpp -- minimal PNG codec for the host I/O either side of the hot path (host only, zlib).
+// csic_png.cpp -- minimal PNG codec for the host I/O either side of the hot path (host only; reading: own inflate /
+// CRC / Adler, csic_inflate.cpp; writing: zlib's deflate).
 //
 // Stands in for the scrimage calls of the reference's helper object:
 //   ImmutableImage.loader().fromFile(file)              ImageProcessorModel.scala:14-16
@@ -11,13 +12,25 @@
 // Supported: non-interlaced PNG, colour types 0/2/3/4/6, bit depths 1/2/4/8/16 (16-bit samples keep
 // their high byte).  The encoder writes 8-bit RGB (what the reference's spec dumps are:
 // BufferedImage.TYPE_INT_RGB, ChromaSubsamplerImageSpec.scala:88) with per-row adaptive filtering.
+//
+// The reader is what bounds the path from files (profiles/r03_host_io.json), so 8-bit RGB / RGBA -- what the reference's
+// inputs and every encoder's default are -- have their own row loops: the Sub / Average filters carry the previous
+// pixel in registers instead of re-loading the bytes just stored, Paeth works on a whole pixel in one SSE2 register,
+// and the conversion to ARGB words is one byte shuffle per four pixels where the CPU has SSSE3.  Everything else
+// (grey, palette, 16-bit, sub-byte depths) takes the plain byte loops.
 #include <zlib.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
+#include <utility>
 #include <vector>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "csic_internal.h"
 
@@ -34,7 +47,15 @@ uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | ((uint32
 
 const unsigned char kSig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
 
-int read_file(const char *path, std::vector<unsigned char> &buf)
+struct FileBytes {                                               // a whole file, not zero-filled first
+    std::unique_ptr<unsigned char[]> mem;
+    size_t len = 0;
+    const unsigned char *data() const { return mem.get(); }
+    size_t size() const { return len; }
+    const unsigned char &operator[](size_t i) const { return mem[i]; }
+};
+
+int read_file(const char *path, FileBytes &buf)
 {
     FILE *fp = std::fopen(path, "rb");
     if (!fp) return set_error(CSIC_EIO, "cannot open %s", path);
@@ -42,16 +63,18 @@ int read_file(const char *path, std::vector<unsigned char> &buf)
     long n = std::ftell(fp);
     std::fseek(fp, 0, SEEK_SET);
     if (n < 0) { std::fclose(fp); return set_error(CSIC_EIO, "cannot size %s", path); }
-    buf.resize((size_t)n);
-    size_t got = n ? std::fread(buf.data(), 1, (size_t)n, fp) : 0;
+    buf.mem.reset(new unsigned char[(size_t)n + 1]);
+    buf.len = (size_t)n;
+    size_t got = n ? std::fread(buf.mem.get(), 1, (size_t)n, fp) : 0;
     std::fclose(fp);
     if (got != (size_t)n) return set_error(CSIC_EIO, "short read on %s", path);
     return CSIC_OK;
 }
 
-// Walks the chunk list: fills the header, the palette and the concatenated IDAT stream.
-int parse(const char *path, const std::vector<unsigned char> &f, Header &hd, std::vector<unsigned char> *plte,
-          std::vector<unsigned char> *idat)
+typedef std::vector<std::pair<const unsigned char *, size_t>> Spans;
+
+// Walks the chunk list: fills the header, the palette and the list of IDAT payloads (pointers into `f`).
+int parse(const char *path, const FileBytes &f, Header &hd, std::vector<unsigned char> *plte, Spans *idat)
 {
     if (f.size() < 8 + 25 || std::memcmp(f.data(), kSig, 8) != 0) return set_error(CSIC_EFORMAT, "%s is not a PNG file", path);
     size_t pos = 8;
@@ -62,7 +85,7 @@ int parse(const char *path, const std::vector<unsigned char> &f, Header &hd, std
         if (pos + 12 + (size_t)len > f.size()) return set_error(CSIC_EFORMAT, "%s: truncated chunk", path);
         const unsigned char *data = &f[pos + 8];
         const uint32_t crc = be32(&f[pos + 8 + len]);
-        if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), type, 4 + len) != crc) return set_error(CSIC_EFORMAT, "%s: chunk CRC mismatch", path);
+        if (crc32_update(0, type, 4 + (size_t)len) != crc) return set_error(CSIC_EFORMAT, "%s: chunk CRC mismatch", path);
         if (!std::memcmp(type, "IHDR", 4)) {
             if (len != 13) return set_error(CSIC_EFORMAT, "%s: bad IHDR", path);
             hd.w = be32(data); hd.h = be32(data + 4);
@@ -72,7 +95,7 @@ int parse(const char *path, const std::vector<unsigned char> &f, Header &hd, std
         } else if (!std::memcmp(type, "PLTE", 4)) {
             if (plte) plte->assign(data, data + len);
         } else if (!std::memcmp(type, "IDAT", 4)) {
-            if (idat) idat->insert(idat->end(), data, data + len);
+            if (idat && len) idat->emplace_back(data, (size_t)len);
         } else if (!std::memcmp(type, "IEND", 4)) {
             have_iend = true;
             break;
@@ -98,12 +121,163 @@ inline int paeth(int a, int b, int c)
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
+// ---- 8-bit RGB / RGBA rows: BPP = 3 / 4 bytes per pixel -------------------------------------------------------------
+template <int BPP> void unfilter_sub(unsigned char *cur, size_t npx)
+{
+    unsigned a[BPP] = {0};
+    for (size_t x = 0; x < npx; ++x, cur += BPP)
+        for (int c = 0; c < BPP; ++c) { a[c] = (a[c] + cur[c]) & 255u; cur[c] = (unsigned char)a[c]; }
+}
+
+template <int BPP> void unfilter_avg(unsigned char *cur, const unsigned char *prev, size_t npx)
+{
+    unsigned a[BPP] = {0};
+    for (size_t x = 0; x < npx; ++x, cur += BPP, prev += BPP)
+        for (int c = 0; c < BPP; ++c) { a[c] = (cur[c] + ((a[c] + prev[c]) >> 1)) & 255u; cur[c] = (unsigned char)a[c]; }
+}
+
+// One pixel per step, its channels in the 16-bit lanes of one register.  Reads 4 bytes per pixel: with BPP = 3 the byte
+// behind a row is the next row's filter byte or the buffer's padding (never stored to; its lane is not used).
+template <int BPP> void unfilter_paeth(unsigned char *cur, const unsigned char *prev, size_t npx)
+{
+#if defined(__x86_64__)
+    const __m128i zero = _mm_setzero_si128(), low = _mm_set1_epi16(0xFF);
+    __m128i a = zero, c = zero;
+    for (size_t x = 0; x < npx; ++x, cur += BPP, prev += BPP) {
+        uint32_t wb, wr;
+        std::memcpy(&wb, prev, 4); std::memcpy(&wr, cur, 4);
+        const __m128i b = _mm_unpacklo_epi8(_mm_cvtsi32_si128((int)wb), zero), r = _mm_unpacklo_epi8(_mm_cvtsi32_si128((int)wr), zero);
+        __m128i pa = _mm_sub_epi16(b, c), pb = _mm_sub_epi16(a, c);                       // p - a, p - b with p = a + b - c
+        __m128i pc = _mm_add_epi16(pa, pb);
+        pa = _mm_max_epi16(pa, _mm_sub_epi16(zero, pa));
+        pb = _mm_max_epi16(pb, _mm_sub_epi16(zero, pb));
+        pc = _mm_max_epi16(pc, _mm_sub_epi16(zero, pc));
+        const __m128i least = _mm_min_epi16(pc, _mm_min_epi16(pa, pb));
+        const __m128i is_a = _mm_cmpeq_epi16(least, pa), is_b = _mm_cmpeq_epi16(least, pb);   // ties: a before b before c
+        const __m128i b_or_c = _mm_or_si128(_mm_and_si128(is_b, b), _mm_andnot_si128(is_b, c));
+        const __m128i pred = _mm_or_si128(_mm_and_si128(is_a, a), _mm_andnot_si128(is_a, b_or_c));
+        a = _mm_and_si128(_mm_add_epi16(r, pred), low);
+        c = b;
+        const uint32_t o = (uint32_t)_mm_cvtsi128_si32(_mm_packus_epi16(a, a));
+        std::memcpy(cur, &o, BPP);
+    }
+#else
+    int a[BPP] = {0}, c[BPP] = {0};
+    for (size_t x = 0; x < npx; ++x, cur += BPP, prev += BPP)
+        for (int k = 0; k < BPP; ++k) { a[k] = (cur[k] + paeth(a[k], prev[k], c[k])) & 255; c[k] = prev[k]; cur[k] = (unsigned char)a[k]; }
+#endif
+}
+
+template <int BPP> void to_argb_scalar(const unsigned char *px, uint32_t *out, size_t npx)
+{
+    for (size_t x = 0; x < npx; ++x, px += BPP) out[x] = 0xFF000000u | ((uint32_t)px[0] << 16) | ((uint32_t)px[1] << 8) | px[2];
+}
+
+#if defined(__x86_64__)
+// 4 pixels per step from one 16-byte load (BPP = 3: 12 of them used, so the steps stop 4 bytes short of the row's end).
+template <int BPP> __attribute__((target("ssse3"))) void to_argb_ssse3(const unsigned char *px, uint32_t *out, size_t npx)
+{
+    const __m128i pick = BPP == 3 ? _mm_setr_epi8(2, 1, 0, -1, 5, 4, 3, -1, 8, 7, 6, -1, 11, 10, 9, -1)
+                                  : _mm_setr_epi8(2, 1, 0, -1, 6, 5, 4, -1, 10, 9, 8, -1, 14, 13, 12, -1);
+    const __m128i alpha = _mm_set1_epi32((int)0xFF000000u);
+    size_t x = 0;
+    for (; (x + 4) * BPP + (16 - 4 * BPP) <= npx * BPP; x += 4)
+        _mm_storeu_si128((__m128i *)(out + x), _mm_or_si128(_mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(px + x * BPP)), pick), alpha));
+    to_argb_scalar<BPP>(px + x * BPP, out + x, npx - x);
+}
+#endif
+
+#if defined(__x86_64__)
+// Average and Paeth are serial in x (about 4 and 11 cycles of dependent arithmetic per pixel), but row y + 1 at pixel x - 1
+// needs of row y only pixels x - 1 and x - 2: two consecutive rows of these filters run as two independent chains in one
+// loop, one pixel apart, and row y + 1 takes its "above" and "above left" from the registers row y has just produced.
+template <int FT> inline __m128i filter_step(__m128i r, __m128i a, __m128i b, __m128i c)   // 16-bit lanes; FT: 3 Average, 4 Paeth
+{
+    const __m128i zero = _mm_setzero_si128(), low = _mm_set1_epi16(0xFF);
+    if (FT == 3) return _mm_and_si128(_mm_add_epi16(r, _mm_srli_epi16(_mm_add_epi16(a, b), 1)), low);
+    __m128i pa = _mm_sub_epi16(b, c), pb = _mm_sub_epi16(a, c);
+    __m128i pc = _mm_add_epi16(pa, pb);
+    pa = _mm_max_epi16(pa, _mm_sub_epi16(zero, pa));
+    pb = _mm_max_epi16(pb, _mm_sub_epi16(zero, pb));
+    pc = _mm_max_epi16(pc, _mm_sub_epi16(zero, pc));
+    const __m128i least = _mm_min_epi16(pc, _mm_min_epi16(pa, pb));
+    const __m128i is_a = _mm_cmpeq_epi16(least, pa), is_b = _mm_cmpeq_epi16(least, pb);
+    const __m128i b_or_c = _mm_or_si128(_mm_and_si128(is_b, b), _mm_andnot_si128(is_b, c));
+    return _mm_and_si128(_mm_add_epi16(r, _mm_or_si128(_mm_and_si128(is_a, a), _mm_andnot_si128(is_a, b_or_c))), low);
+}
+
+inline __m128i load_px(const unsigned char *p) { uint32_t w; std::memcpy(&w, p, 4); return _mm_unpacklo_epi8(_mm_cvtsi32_si128((int)w), _mm_setzero_si128()); }
+template <int BPP> inline void store_px(unsigned char *p, __m128i v) { const uint32_t o = (uint32_t)_mm_cvtsi128_si32(_mm_packus_epi16(v, v)); std::memcpy(p, &o, BPP); }
+
+template <int BPP, int FT0, int FT1> void unfilter_two_rows(unsigned char *cur0, unsigned char *cur1, const unsigned char *prev, size_t npx)
+{
+    const __m128i zero = _mm_setzero_si128();
+    __m128i c0 = load_px(prev), a0 = filter_step<FT0>(load_px(cur0), zero, c0, zero);    // row 0, pixel 0
+    store_px<BPP>(cur0, a0);
+    __m128i a1 = zero, c1 = zero;
+    for (size_t x = 1; x < npx; ++x) {
+        const __m128i b0 = load_px(prev + x * BPP);
+        const __m128i n0 = filter_step<FT0>(load_px(cur0 + x * BPP), a0, b0, c0);       // row 0, pixel x
+        a1 = filter_step<FT1>(load_px(cur1 + (x - 1) * BPP), a1, a0, c1);               // row 1, pixel x - 1: above = a0, above left = c1
+        store_px<BPP>(cur0 + x * BPP, n0);
+        store_px<BPP>(cur1 + (x - 1) * BPP, a1);
+        c1 = a0; c0 = b0; a0 = n0;
+    }
+    a1 = filter_step<FT1>(load_px(cur1 + (npx - 1) * BPP), a1, a0, c1);
+    store_px<BPP>(cur1 + (npx - 1) * BPP, a1);
+}
+
+template <int BPP> void unfilter_two_rows(int ft0, int ft1, unsigned char *cur0, unsigned char *cur1, const unsigned char *prev, size_t npx)
+{
+    if (ft0 == 3) { if (ft1 == 3) unfilter_two_rows<BPP, 3, 3>(cur0, cur1, prev, npx); else unfilter_two_rows<BPP, 3, 4>(cur0, cur1, prev, npx); }
+    else          { if (ft1 == 3) unfilter_two_rows<BPP, 4, 3>(cur0, cur1, prev, npx); else unfilter_two_rows<BPP, 4, 4>(cur0, cur1, prev, npx); }
+}
+#endif
+
+template <int BPP> int decode_rows_8bit(const char *path, unsigned char *raw, size_t W, size_t H, uint32_t *dst, const unsigned char *zero_row)
+{
+    const size_t stride = W * BPP;
+#if defined(__x86_64__)
+    static const bool have_ssse3 = __builtin_cpu_supports("ssse3");
+#endif
+    auto emit = [&](const unsigned char *px, size_t y) {
+#if defined(__x86_64__)
+        if (have_ssse3) { to_argb_ssse3<BPP>(px, dst + y * W, W); return; }
+#endif
+        to_argb_scalar<BPP>(px, dst + y * W, W);
+    };
+    for (size_t y = 0; y < H; ++y) {
+        unsigned char *cur = raw + y * (stride + 1) + 1;
+        const unsigned char *prev = y ? cur - (stride + 1) : zero_row;
+        const int ft = cur[-1];
+#if defined(__x86_64__)
+        if ((ft == 3 || ft == 4) && y + 1 < H && (cur[stride] == 3 || cur[stride] == 4)) {       // cur[stride]: the next row's filter byte
+            unfilter_two_rows<BPP>(ft, cur[stride], cur, cur + stride + 1, prev, W);
+            emit(cur, y);
+            emit(cur + stride + 1, y + 1);
+            ++y;
+            continue;
+        }
+#endif
+        switch (ft) {
+        case 0: break;
+        case 1: unfilter_sub<BPP>(cur, W); break;
+        case 2: for (size_t i = 0; i < stride; ++i) cur[i] = (unsigned char)(cur[i] + prev[i]); break;
+        case 3: unfilter_avg<BPP>(cur, prev, W); break;
+        case 4: unfilter_paeth<BPP>(cur, prev, W); break;
+        default: return set_error(CSIC_EFORMAT, "%s: bad filter type %d", path, ft);
+        }
+        emit(cur, y);
+    }
+    return CSIC_OK;
+}
+
 } // namespace
 
 static int png_info_impl(const char *path, int32_t *width, int32_t *height)
 {
     if (!path || !width || !height) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
-    std::vector<unsigned char> f;
+    FileBytes f;
     int st = read_file(path, f);
     if (st != CSIC_OK) return st;
     Header hd;
@@ -117,7 +291,9 @@ static int png_info_impl(const char *path, int32_t *width, int32_t *height)
 static int png_read_impl(const char *path, uint32_t *dst, size_t dst_px)
 {
     if (!path || !dst) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
-    std::vector<unsigned char> f, plte, idat;
+    FileBytes f;
+    std::vector<unsigned char> plte, joined;
+    Spans idat;
     int st = read_file(path, f);
     if (st != CSIC_OK) return st;
     Header hd;
@@ -129,16 +305,33 @@ static int png_read_impl(const char *path, uint32_t *dst, size_t dst_px)
     const size_t bits_pp = (size_t)nch * hd.depth;
     const size_t stride = (W * bits_pp + 7) / 8;
     const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;           // filter distance in bytes
-    std::vector<unsigned char> raw((stride + 1) * H);
-    uLongf rawlen = (uLongf)raw.size();
-    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size())
-        return set_error(CSIC_EFORMAT, "%s: corrupt image data", path);
+    const unsigned char *z = nullptr;
+    size_t zlen = 0;
+    if (idat.size() == 1) { z = idat[0].first; zlen = idat[0].second; }   // one IDAT chunk: decode it where it lies
+    else {
+        for (const auto &sp : idat) zlen += sp.second;
+        joined.reserve(zlen);
+        for (const auto &sp : idat) joined.insert(joined.end(), sp.first, sp.first + sp.second);
+        z = joined.data();
+    }
+    const size_t rawlen = (stride + 1) * H, pad = 16;                     // the padding: see unfilter_paeth
+    std::unique_ptr<unsigned char[]> rawbuf(new unsigned char[rawlen + pad]);
+    unsigned char *raw = rawbuf.get();
+    std::memset(raw + rawlen, 0, pad);
+    if (zlib_decode_exact(z, zlen, raw, rawlen) != 0) return set_error(CSIC_EFORMAT, "%s: corrupt image data", path);
     if (hd.ctype == 3 && plte.size() < 3) return set_error(CSIC_EFORMAT, "%s: palette image without PLTE", path);
-    std::vector<unsigned char> prev(stride, 0);
+    const std::vector<unsigned char> zero_row(stride + pad, 0);
+    if (hd.depth == 8 && (hd.ctype == 2 || hd.ctype == 6)) {
+        st = hd.ctype == 2 ? decode_rows_8bit<3>(path, raw, W, H, dst, zero_row.data()) : decode_rows_8bit<4>(path, raw, W, H, dst, zero_row.data());
+        if (st != CSIC_OK) return st;
+        clear_error();
+        return CSIC_OK;
+    }
     for (size_t y = 0; y < H; ++y) {
         unsigned char *row = &raw[y * (stride + 1)];
         const int ft = row[0];
         unsigned char *cur = row + 1;
+        const unsigned char *prev = y ? cur - (stride + 1) : zero_row.data();
         switch (ft) {
         case 0: break;
         case 1: for (size_t i = bpp; i < stride; ++i) cur[i] = (unsigned char)(cur[i] + cur[i - bpp]); break;
@@ -173,7 +366,6 @@ static int png_read_impl(const char *path, uint32_t *dst, size_t dst_px)
             }
             out[x] = 0xFF000000u | (r << 16) | (g << 8) | b;
         }
-        std::memcpy(prev.data(), cur, stride);
     }
     clear_error();
     return CSIC_OK;
@@ -184,29 +376,40 @@ static int png_write_impl(const char *path, const uint32_t *src, int32_t width, 
     if (!path || !src) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
     if (width <= 0 || height <= 0) return set_error(CSIC_EINVAL_DIMS, "width and height must be positive. Got %dx%d", width, height);
     if (level < 0 || level > 9) level = 6;
-    const size_t W = (size_t)width, H = (size_t)height, stride = W * 3;
-    std::vector<unsigned char> raw((stride + 1) * H), cur(stride), prev(stride, 0), cand(stride);
+    const size_t W = (size_t)width, H = (size_t)height, stride = W * 3, lead = 16;
+    // Rows carry `lead` zero bytes in front (the pixels "left of the image"), so every candidate is one loop without edge
+    // cases that the compiler vectorises: the filters of an encoder work on ORIGINAL pixels, nothing is serial here.
+    std::vector<unsigned char> raw((stride + 1) * H), row_a(lead + stride, 0), row_b(lead + stride, 0), cand(5 * stride);
+    unsigned char *cur = row_a.data() + lead, *prev = row_b.data() + lead;
     for (size_t y = 0; y < H; ++y) {
         for (size_t x = 0; x < W; ++x) {
             const uint32_t v = src[y * W + x];
             cur[3 * x] = (unsigned char)(v >> 16); cur[3 * x + 1] = (unsigned char)(v >> 8); cur[3 * x + 2] = (unsigned char)v;
         }
-        // adaptive filtering: minimum sum of absolute (signed) residuals
-        int best_ft = 0; unsigned long best = ~0ul;
-        unsigned char *row = &raw[y * (stride + 1)];
-        for (int ft = 0; ft < 5; ++ft) {
-            unsigned long sum = 0;
-            for (size_t i = 0; i < stride; ++i) {
-                const int a = i >= 3 ? cur[i - 3] : 0, b = prev[i], c = i >= 3 ? prev[i - 3] : 0;
-                const int pred = ft == 0 ? 0 : ft == 1 ? a : ft == 2 ? b : ft == 3 ? ((a + b) >> 1) : paeth(a, b, c);
-                const unsigned char d = (unsigned char)(cur[i] - pred);
-                cand[i] = d;
-                sum += d < 128 ? d : 256 - d;
-            }
-            if (sum < best) { best = sum; best_ft = ft; row[0] = (unsigned char)ft; std::memcpy(row + 1, cand.data(), stride); }
+        unsigned char *c0 = cand.data(), *c1 = c0 + stride, *c2 = c1 + stride, *c3 = c2 + stride, *c4 = c3 + stride;
+        const unsigned char *left = cur - 3, *up_left = prev - 3;
+        for (size_t i = 0; i < stride; ++i) c0[i] = cur[i];
+        for (size_t i = 0; i < stride; ++i) c1[i] = (unsigned char)(cur[i] - left[i]);
+        for (size_t i = 0; i < stride; ++i) c2[i] = (unsigned char)(cur[i] - prev[i]);
+        for (size_t i = 0; i < stride; ++i) c3[i] = (unsigned char)(cur[i] - ((left[i] + prev[i]) >> 1));
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = left[i], b = prev[i], c = up_left[i];
+            const int pa = b > c ? b - c : c - b, pb = a > c ? a - c : c - a, pc = a + b > 2 * c ? a + b - 2 * c : 2 * c - a - b;
+            const int pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            c4[i] = (unsigned char)(cur[i] - pred);
         }
-        (void)best_ft;
-        prev = cur;
+        // adaptive filtering: minimum sum of absolute (signed) residuals, the first of equal sums
+        int best_ft = 0; unsigned long best = ~0ul;
+        for (int ft = 0; ft < 5; ++ft) {
+            const unsigned char *c = cand.data() + (size_t)ft * stride;
+            unsigned long sum = 0;
+            for (size_t i = 0; i < stride; ++i) sum += c[i] < 128 ? c[i] : 256 - c[i];
+            if (sum < best) { best = sum; best_ft = ft; }
+        }
+        unsigned char *row = &raw[y * (stride + 1)];
+        row[0] = (unsigned char)best_ft;
+        std::memcpy(row + 1, cand.data() + (size_t)best_ft * stride, stride);
+        std::swap(cur, prev);
     }
     uLongf clen = compressBound((uLong)raw.size());
     std::vector<unsigned char> comp(clen);

@@ -39,6 +39,96 @@ static void resign(std::vector<unsigned char> &png)      // recompute every chun
     }
 }
 
+// csic_inflate.cpp against zlib itself: streams of every block type, level, strategy, window and block size must decode
+// to the same bytes; mutated streams must be accepted or rejected exactly as uncompress() does, byte-identical where
+// accepted; crc32_update / adler32_update must agree with zlib's on every length, offset and chaining.
+static int check_inflate()
+{
+    long streams = 0, mutated = 0, accepted = 0;
+    std::vector<unsigned char> src, comp, got, ref;
+    for (int it = 0; it < 700; ++it) {
+        const unsigned kind = rnd() % 8;
+        size_t n = rnd() % 8 == 0 ? rnd() % 40 : rnd() % 4 == 0 ? 100000 + rnd() % 200000 : rnd() % 20000;
+        src.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            switch (kind) {
+            case 0: src[i] = (unsigned char)rnd(); break;                                             // incompressible
+            case 1: src[i] = (unsigned char)("the quick brown fox "[rnd() % 20]); break;
+            case 2: src[i] = (unsigned char)(i / 977); break;                                         // long runs
+            case 3: src[i] = i >= 3 && rnd() % 16 ? src[i - 3] : (unsigned char)rnd(); break;         // distance 3, PNG-like
+            case 4: src[i] = (unsigned char)((rnd() % 7) - 3); break;                                 // filter residuals
+            case 5: src[i] = 0; break;
+            case 6: src[i] = i >= 4 && rnd() % 64 ? (unsigned char)(src[i - 4] + (rnd() % 3) - 1) : (unsigned char)rnd(); break;
+            default: { const size_t d = 1 + (it % 40000); src[i] = i >= d && rnd() % 200 ? src[i - d] : (unsigned char)rnd(); break; }
+            }
+        }
+        static const int strategies[] = {Z_DEFAULT_STRATEGY, Z_FILTERED, Z_HUFFMAN_ONLY, Z_RLE, Z_FIXED};
+        z_stream zs;
+        std::memset(&zs, 0, sizeof zs);
+        const int level = (int)(rnd() % 10), wbits = 9 + (int)(rnd() % 7), mem = 1 + (int)(rnd() % 9);
+        if (deflateInit2(&zs, level, Z_DEFLATED, wbits, mem, strategies[rnd() % 5]) != Z_OK) { std::printf("deflateInit2 failed\n"); return 1; }
+        comp.resize(deflateBound(&zs, (uLong)n) + 64);
+        zs.next_in = src.data(); zs.avail_in = (uInt)n; zs.next_out = comp.data(); zs.avail_out = (uInt)comp.size();
+        if (rnd() % 3 == 0 && n > 10) {                                                               // a flush point in the middle: empty stored block
+            zs.avail_in = (uInt)(n / 2);
+            deflate(&zs, rnd() % 2 ? Z_SYNC_FLUSH : Z_FULL_FLUSH);
+            zs.avail_in = (uInt)(n - n / 2);
+        }
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { std::printf("deflate failed\n"); return 1; }
+        comp.resize(zs.total_out);
+        deflateEnd(&zs);
+        got.assign(n + 1, 0xA5);
+        int st = csic::zlib_decode_exact(comp.data(), comp.size(), got.data(), n);
+        if (st != 0 || std::memcmp(got.data(), src.data(), n) != 0 || got[n] != 0xA5) {
+            std::printf("inflate mismatch: status %d, n %zu level %d wbits %d mem %d kind %u\n", st, n, level, wbits, mem, kind);
+            return 1;
+        }
+        if (csic::zlib_decode_exact(comp.data(), comp.size(), got.data(), n + 1) != 4) { std::printf("a short stream was accepted\n"); return 1; }
+        if (n && csic::zlib_decode_exact(comp.data(), comp.size(), got.data(), n - 1) != 3) { std::printf("a long stream was accepted\n"); return 1; }
+        for (size_t cut = comp.size() > 12 ? comp.size() - 12 : 0; cut < comp.size(); ++cut)          // truncations near the end
+            if (csic::zlib_decode_exact(comp.data(), cut, got.data(), n) == 0) { std::printf("a truncated stream was accepted\n"); return 1; }
+        ++streams;
+        for (int m = 0; m < 12; ++m) {
+            std::vector<unsigned char> mu = comp;
+            const int nmut = 1 + rnd() % 3;
+            for (int k = 0; k < nmut; ++k) {
+                const size_t pos = rnd() % mu.size();
+                if (rnd() % 2) mu[pos] ^= 1u << (rnd() % 8); else mu[pos] = (unsigned char)rnd();
+            }
+            if (rnd() % 8 == 0) mu.resize(1 + rnd() % mu.size());
+            ref.assign(n, 0);
+            uLongf rl = (uLongf)n;
+            unsigned char dummy = 0;
+            const int zr = uncompress(n ? ref.data() : &dummy, &rl, mu.data(), (uLong)mu.size());
+            const bool z_ok = zr == Z_OK && rl == n;
+            got.assign(n + 1, 0xA5);
+            st = csic::zlib_decode_exact(mu.data(), mu.size(), got.data(), n);
+            if (got[n] != 0xA5) { std::printf("wrote past the output\n"); return 1; }
+            if ((st == 0) != z_ok) { std::printf("mutated stream: zlib %d (len %lu of %zu), ours %d\n", zr, (unsigned long)rl, n, st); return 1; }
+            if (z_ok && std::memcmp(got.data(), ref.data(), n) != 0) { std::printf("mutated stream decodes differently\n"); return 1; }
+            accepted += z_ok;
+            ++mutated;
+        }
+    }
+    std::vector<unsigned char> buf(70000);
+    for (auto &b : buf) b = (unsigned char)rnd();
+    for (int it = 0; it < 3000; ++it) {
+        const size_t off = rnd() % 64, n = it < 300 ? (size_t)it : rnd() % (buf.size() - off), cut = n ? rnd() % (n + 1) : 0;
+        const unsigned char *p = buf.data() + off;
+        const uint32_t c = csic::crc32_update(csic::crc32_update(0, p, cut), p + cut, n - cut);
+        const uint32_t a = csic::adler32_update(csic::adler32_update(1, p, cut), p + cut, n - cut);
+        if (c != (uint32_t)crc32(crc32(0, Z_NULL, 0), p, (uInt)n) || a != (uint32_t)adler32(adler32(0, Z_NULL, 0), p, (uInt)n)) {
+            std::printf("checksum mismatch at off %zu n %zu\n", off, n);
+            return 1;
+        }
+    }
+    std::memset(buf.data(), 0xFF, buf.size());                                                        // the sums' worst case
+    if (csic::adler32_update(0xFFF0FFF0u % 65521u | ((0xFFF0u % 65521u) << 16), buf.data(), buf.size()) !=
+        (uint32_t)adler32(0xFFF0FFF0u % 65521u | ((0xFFF0u % 65521u) << 16), buf.data(), (uInt)buf.size())) { std::printf("adler overflow\n"); return 1; }
+    std::printf("inflate ok: %ld streams, %ld mutated (%ld still valid)\n", streams, mutated, accepted);
+    return 0;
+}
+
 // magic_div must reproduce the hardware divide for every dividend below 2^31
 static int check_magic_div()
 {
@@ -161,6 +251,7 @@ int main(int argc, char **argv)
         (void)csic_strerror(st); (void)csic_last_error();
         ++checked;
     }
+    if (check_inflate() != 0) return 1;
     // ---- PNG codec: round trip, then mutation fuzzing of every fixture given on the command line
     std::vector<uint32_t> img(37 * 23);
     for (auto &v : img) v = rnd();

@@ -65,40 +65,75 @@ def test_low_bit_depths_and_16_bit(tmp_path):
     assert np.array_equal(got[..., 0], (g16 >> 8).astype(np.uint8)) and np.array_equal(got[..., 0], got[..., 2])
 
 
-def test_all_filter_types_are_unfiltered(tmp_path):
-    """Hand-built PNGs that force each of the five row filters."""
+def _png_with_filters(pixels, filters):
+    """A PNG of `pixels` (H x W x 3 or 4, uint8) whose row y uses filter type filters[y]."""
     import struct
     import zlib
+    H, W, C = pixels.shape
+    raw = bytearray()
+    prev = np.zeros(W * C, np.int32)
+    for y in range(H):
+        ft = filters[y]
+        cur = pixels[y].reshape(-1).astype(np.int32)
+        a = np.concatenate([np.zeros(C, np.int32), cur[:-C]])
+        c = np.concatenate([np.zeros(C, np.int32), prev[:-C]])
+        if ft == 0: pred = np.zeros_like(cur)
+        elif ft == 1: pred = a
+        elif ft == 2: pred = prev
+        elif ft == 3: pred = (a + prev) >> 1
+        else:
+            pp = a + prev - c
+            pa, pb, pc = np.abs(pp - a), np.abs(pp - prev), np.abs(pp - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        raw.append(ft)
+        raw += bytes(((cur - pred) & 0xFF).astype(np.uint8))
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    z = zlib.compress(bytes(raw))
+    cut = len(z) // 3                                              # three IDAT chunks: the stream is split anywhere
+    return (bytes([0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A]) + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2 if C == 3 else 6, 0, 0, 0))
+            + chunk(b"IDAT", z[:cut]) + chunk(b"IDAT", z[cut:2 * cut]) + chunk(b"IDAT", z[2 * cut:]) + chunk(b"IEND", b""))
+
+
+def test_all_filter_types_are_unfiltered(tmp_path):
+    """Hand-built PNGs that force each of the five row filters."""
     rng = np.random.default_rng(4)
     W, H = 21, 11
     rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
     for ft in range(5):
-        raw = bytearray()
-        prev = np.zeros(W * 3, np.int32)
-        for y in range(H):
-            cur = rgb[y].reshape(-1).astype(np.int32)
-            a = np.concatenate([np.zeros(3, np.int32), cur[:-3]])
-            c = np.concatenate([np.zeros(3, np.int32), prev[:-3]])
-            if ft == 0: pred = np.zeros_like(cur)
-            elif ft == 1: pred = a
-            elif ft == 2: pred = prev
-            elif ft == 3: pred = (a + prev) >> 1
-            else:
-                pp = a + prev - c
-                pa, pb, pc = np.abs(pp - a), np.abs(pp - prev), np.abs(pp - c)
-                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
-            raw.append(ft)
-            raw += bytes(((cur - pred) & 0xFF).astype(np.uint8))
-            prev = cur
-
-        def chunk(t, d):
-            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
-        data = (bytes([0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A]) + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0))
-                + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
         p = tmp_path / f"f{ft}.png"
-        p.write_bytes(data)
+        p.write_bytes(_png_with_filters(rgb, [ft] * H))
         assert np.array_equal(np.asarray(PILImage.open(p).convert("RGB")), rgb)      # the file is valid
         assert np.array_equal(M.readImage(str(p)).rgb(), rgb), ft
+
+
+@pytest.mark.parametrize("channels", [3, 4])
+def test_every_sequence_of_row_filters(tmp_path, channels):
+    """The reader unfilters consecutive Average / Paeth rows two at a time (RGB and RGBA have their own loops): every
+    ordered pair of filter types must appear at even and odd rows, at the first and the last row, at widths from one pixel up,
+    on noisy and on smooth pixels (where Paeth's ties decide)."""
+    rng = np.random.default_rng(40 + channels)
+    order = [f for a in range(5) for b in range(5) for f in (a, b)]              # 25 ordered pairs back to back
+    for W in (1, 2, 3, 4, 5, 6, 7, 16, 21, 64):
+        for shift in (0, 1):
+            filters = ([3] if shift else []) + order + [4, 4, 3, 3, 4, 3, 3, 4, 4, 4]
+            H = len(filters)
+            px = rng.integers(0, 256, (H, W, channels), dtype=np.uint8)
+            if W >= 16:                                                           # smooth halves: equal neighbours, Paeth ties
+                px[: H // 2] = (np.arange(W)[None, :, None] * 3 + np.arange(H // 2)[:, None, None]).astype(np.uint8)
+            p = tmp_path / f"s{W}_{shift}.png"
+            p.write_bytes(_png_with_filters(px, filters))
+            want = np.asarray(PILImage.open(p).convert("RGB"))
+            assert np.array_equal(want, px[..., :3])
+            assert np.array_equal(M.readImage(str(p)).rgb(), want), (W, shift)
+        for last in (3, 4):                                                       # an odd row count ending in a lone Average / Paeth row
+            filters = [4, 3, last]
+            px = rng.integers(0, 256, (3, W, channels), dtype=np.uint8)
+            p = tmp_path / f"t{W}_{last}.png"
+            p.write_bytes(_png_with_filters(px, filters))
+            assert np.array_equal(M.readImage(str(p)).rgb(), px[..., :3]), (W, last)
 
 
 def test_error_paths(tmp_path):
