@@ -19,6 +19,7 @@
 // Checked against zlib itself (uncompress / crc32 / adler32) on random streams of every block type and level, and on
 // mutated streams, under ASan / UBSan in tests/cpp/host_sanitize.cpp.
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #if defined(__x86_64__)
@@ -416,7 +417,7 @@ uint32_t crc32_update(uint32_t crc, const unsigned char *p, size_t n)
 {
     uint32_t c = ~crc;
 #if defined(__x86_64__)
-    static const bool have_clmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+    static const bool have_clmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !std::getenv("CSIC_NO_SIMD");   // (the variable: tests of the portable paths)
     if (have_clmul && n >= 64) {
         const size_t body = n & ~(size_t)15;
         c = crc32_clmul(c, p, body);
@@ -437,7 +438,7 @@ uint32_t crc32_update(uint32_t crc, const unsigned char *p, size_t n)
 uint32_t adler32_update(uint32_t adler, const unsigned char *p, size_t n)
 {
 #if defined(__x86_64__)
-    static const bool have_ssse3 = __builtin_cpu_supports("ssse3");
+    static const bool have_ssse3 = __builtin_cpu_supports("ssse3") && !std::getenv("CSIC_NO_SIMD");
     if (have_ssse3) return adler32_ssse3(adler, p, n);
 #endif
     return adler32_scalar(adler, p, n);

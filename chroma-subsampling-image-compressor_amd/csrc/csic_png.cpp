@@ -238,7 +238,7 @@ template <int BPP> int decode_rows_8bit(const char *path, unsigned char *raw, si
 {
     const size_t stride = W * BPP;
 #if defined(__x86_64__)
-    static const bool have_ssse3 = __builtin_cpu_supports("ssse3");
+    static const bool have_ssse3 = __builtin_cpu_supports("ssse3") && !std::getenv("CSIC_NO_SIMD");   // (the variable: tests of the portable loop)
 #endif
     auto emit = [&](const unsigned char *px, size_t y) {
 #if defined(__x86_64__)

@@ -331,13 +331,15 @@ int  csic_frame_graph_launch_branches(const csic_frame_graph *graph);           
 int  csic_frame_graph_stream_ordered(const csic_frame_graph *graph);               /* 1: launch() is asynchronous and ordered with its stream */
 int  csic_frame_graph_destroy(csic_frame_graph *graph);
 
-/* ---- PNG files (host only, zlib) --------------------------------------------------------------------
+/* ---- PNG files (host only; reading: the library's own inflate, writing: zlib) ------------------------
  * The codec either side of the path: stands in for scrimage's loader / PngWriter behind
  * ImageProcessorModel.readImage / writeImage (ImageProcessorModel.scala:14-22).  Decoding yields straight
  * 8-bit samples as ARGB ints with alpha = 255 (input alpha dropped, gAMA/cHRM not applied -- the behaviour
  * the reference's golden images pin) and writes directly into `dst`, which may be a pinned
  * buffer from csic_pipeline_acquire_input.  Non-interlaced PNGs of every colour type / bit depth are read;
- * 8-bit RGB is written (`level` = zlib level 0..9). */
+ * 8-bit RGB is written (`level` = zlib level 0..9; at level 1 a frame encodes about four times faster than at 6).
+ * The reader accepts and rejects exactly what zlib's inflate does (csrc/csic_inflate.cpp); environment variable
+ * CSIC_NO_SIMD=1 keeps it off the PCLMULQDQ / SSSE3 paths it otherwise takes where the CPU has them. */
 int  csic_png_info(const char *path, int32_t *width, int32_t *height);
 int  csic_png_read_argb(const char *path, uint32_t *dst, size_t dst_px);
 int  csic_png_write_argb(const char *path, const uint32_t *src, int32_t width, int32_t height, int32_t level);

@@ -136,6 +136,80 @@ def test_every_sequence_of_row_filters(tmp_path, channels):
             assert np.array_equal(M.readImage(str(p)).rgb(), px[..., :3]), (W, last)
 
 
+def test_every_kind_of_deflate_stream(tmp_path):
+    """The reader has its own inflate: IDAT streams of every level, strategy and window size (stored, fixed and dynamic blocks,
+    flush points, several IDAT chunks) over noisy, smooth and flat pixels must decode to what Pillow (zlib) decodes."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(77)
+    W, H = 97, 61
+    yy, xx = np.mgrid[0:H, 0:W]
+    images = {"noise": rng.integers(0, 256, (H, W, 3), dtype=np.uint8),
+              "smooth": np.stack([xx * 2, yy * 3, xx + yy], -1).astype(np.uint8),
+              "flat": np.full((H, W, 3), 200, np.uint8),
+              "grain": (np.stack([xx, yy, xx ^ yy], -1) + rng.integers(0, 4, (H, W, 3))).astype(np.uint8)}
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    n = 0
+    for name, px in images.items():
+        raw = b"".join(bytes([y % 5]) + bytes(r) for y, r in enumerate(_filtered_rows(px)))
+        for level in (0, 1, 4, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+                for wbits in (9, 12, 15):
+                    co = zlib.compressobj(level, zlib.DEFLATED, wbits, 1 + (n % 9), strategy)
+                    z = co.compress(raw[: len(raw) // 2]) + co.flush(zlib.Z_SYNC_FLUSH if n % 2 else zlib.Z_FULL_FLUSH) + co.compress(raw[len(raw) // 2:]) + co.flush()
+                    cuts = sorted(set(int(c) for c in rng.integers(0, len(z) + 1, n % 4)))
+                    parts = [z[a:b] for a, b in zip([0] + cuts, cuts + [len(z)])]
+                    data = (bytes([0x89, 0x50, 0x4E, 0x47, 0x0D, 0x0A, 0x1A, 0x0A]) + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0))
+                            + b"".join(chunk(b"IDAT", part) for part in parts) + chunk(b"IEND", b""))
+                    p = tmp_path / "z.png"
+                    p.write_bytes(data)
+                    assert np.array_equal(M.readImage(str(p)).rgb(), px), (name, level, strategy, wbits)
+                    n += 1
+    assert n == 4 * 5 * 5 * 3
+
+
+def _filtered_rows(px):
+    """Rows of `px`, row y filtered with type y % 5."""
+    H, W, C = px.shape
+    prev = np.zeros(W * C, np.int32)
+    for y in range(H):
+        cur = px[y].reshape(-1).astype(np.int32)
+        a = np.concatenate([np.zeros(C, np.int32), cur[:-C]])
+        c = np.concatenate([np.zeros(C, np.int32), prev[:-C]])
+        ft = y % 5
+        pp = a + prev - c
+        pa, pb, pc = np.abs(pp - a), np.abs(pp - prev), np.abs(pp - c)
+        pred = [np.zeros_like(cur), a, prev, (a + prev) >> 1, np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))][ft]
+        yield ((cur - pred) & 0xFF).astype(np.uint8)
+        prev = cur
+
+
+def test_portable_paths_decode_the_same(tmp_path):
+    """CSIC_NO_SIMD=1 turns off the PCLMULQDQ / SSSE3 paths of the reader (CRC-32, Adler-32, ARGB conversion): the
+    reference's own files and a large noisy frame must decode identically through the table / scalar loops."""
+    import subprocess
+    import sys
+    big = tmp_path / "big.png"
+    rng = np.random.default_rng(5)
+    M.writeImage(csic.Image.from_rgb(rng.integers(0, 256, (300, 401, 3), dtype=np.uint8)), str(big), compression=1)
+    files = FIXTURES[:6] + [str(big)]
+    code = ("import sys, zlib, numpy as np, csic_amd as csic\n"
+            "for p in sys.argv[1:]:\n"
+            "    print(zlib.crc32(np.ascontiguousarray(csic.ImageProcessorModel.readImage(p).argb).tobytes()))\n")
+    outs = []
+    for no_simd in ("", "1"):
+        env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        env.pop("CSIC_NO_SIMD", None)
+        if no_simd:
+            env["CSIC_NO_SIMD"] = "1"
+        r = subprocess.run([sys.executable, "-c", code, *files], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.split())
+    assert len(outs[0]) == len(files) and outs[0] == outs[1]
+
+
 def test_error_paths(tmp_path):
     with pytest.raises(csic.CsicIOError) as ei:
         M.readImage(str(tmp_path / "missing.png"))

@@ -20,6 +20,9 @@ def test_host_code_under_asan_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe, str(tmp_path), *files], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "sanitize ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    # once more through the portable loops (no PCLMULQDQ CRC, no SSSE3 Adler-32 / ARGB conversion)
+    r = subprocess.run([exe, str(tmp_path), *files], capture_output=True, text=True, timeout=600, env=dict(env, CSIC_NO_SIMD="1"))
+    assert r.returncode == 0 and "sanitize ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_oracle_under_asan_ubsan(tmp_path):
