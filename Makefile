@@ -19,13 +19,13 @@ asm:
 
 ubench: build
 	/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -I$(PKG)/csrc tools/ubench.hip \
-		$(PKG)/csrc/csic_host.cpp $(PKG)/csrc/csic_png.cpp $(PKG)/csrc/csic_inflate.cpp -lz -o tools/ubench
+		$(PKG)/csrc/csic_host.cpp $(PKG)/csrc/csic_png.cpp $(PKG)/csrc/csic_inflate.cpp -lz -pthread -o tools/ubench
 
 # every developer micro-benchmark under tools/ (binaries are git-ignored; they travel to the GPU box with gpurun)
 HIPCC_TOOL = /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -I$(PKG)/csrc
 tools: ubench
 	for t in ubench_k ubench_overlap ubench_aql ubench_order; do \
-		$(HIPCC_TOOL) tools/$$t.hip $(PKG)/csrc/csic_host.cpp $(PKG)/csrc/csic_png.cpp $(PKG)/csrc/csic_inflate.cpp -lz -L/opt/rocm/lib -lhsa-runtime64 -o tools/$$t || exit 1; done
+		$(HIPCC_TOOL) tools/$$t.hip $(PKG)/csrc/csic_host.cpp $(PKG)/csrc/csic_png.cpp $(PKG)/csrc/csic_inflate.cpp -lz -pthread -L/opt/rocm/lib -lhsa-runtime64 -o tools/$$t || exit 1; done
 	$(HIPCC_TOOL) tools/ubench_rows.hip -o tools/ubench_rows
 
 clean:

@@ -2,8 +2,8 @@
 //
 // The reference handles one image at a time on one thread: readImage -> per-pixel poke ... peek -> writeImage
 // (ImageProcessorModel.scala:14-52, ImageCompressorTopApp.scala:39-41,133-144).  Once the kernel runs at the HBM roofline the
-// PNG codec is everything: one host thread decodes a 4K frame at ~160 Mpixel/s and encodes at ~50, the kernel moves
-// 4.8 Tpixel/s (profiles/r02_host_io.json).  So the step either side of the path is a pool: `decode_threads` workers inflate
+// PNG codec is everything: one host thread decodes a 4K frame at ~160 Mpixel/s (round 2, zlib; ~330 with the reader's own
+// inflate, csic_inflate.cpp) and encodes at ~50, the kernel moves 4.8 Tpixel/s (profiles/r02_host_io.json).  So the step either side of the path is a pool: `decode_threads` workers inflate
 // files STRAIGHT INTO pinned frame slots and launch the fused kernel on the slot's own stream (zero-copy: it reads the pinned
 // frame over PCIe and writes the pinned result, dead rows never cross the bus), `encode_threads` workers wait for a slot's
 // event and deflate its result to the output file.  Slots are the bounded queue between the two pools: a decoder that finds
@@ -179,7 +179,7 @@ void encoder(Shared &sh)
                 std::memcpy(cropped.data(), s.h_out, keep * 4);
                 src = cropped.data();
             }
-            const int st = csic_png_write_argb(sh.out_paths[i], src, sh.final_w, sh.final_h, sh.level);
+            const int st = png_write_argb_threads(sh.out_paths[i], src, sh.final_w, sh.final_h, sh.level, 1);   // the pool is the parallelism
             t_enc += secs(e0, Clock::now());
             if (st != CSIC_OK) fail(sh, st, std::string("file ") + std::to_string(i) + ": " + csic_last_error());
             else ++files;

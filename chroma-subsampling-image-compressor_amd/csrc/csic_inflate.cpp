@@ -139,7 +139,10 @@ struct StaticInit {
 };
 const StaticInit g_static_init;
 
-inline uint64_t load64(const unsigned char *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }   // little-endian host (x86-64)
+#if !defined(__BYTE_ORDER__) || __BYTE_ORDER__ != __ORDER_LITTLE_ENDIAN__
+#error "the bit buffer of this decoder is refilled with little-endian 8-byte loads"
+#endif
+inline uint64_t load64(const unsigned char *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
 inline void store64(unsigned char *p, uint64_t v) { std::memcpy(p, &v, 8); }
 inline void store16(unsigned char *p, uint32_t v) { const uint16_t h = (uint16_t)v; std::memcpy(p, &h, 2); }
 

@@ -35,4 +35,8 @@ int      zlib_decode_exact(const unsigned char *in, size_t in_len, unsigned char
 uint32_t crc32_update(uint32_t crc, const unsigned char *p, size_t n);      // crc32_update(0, ..) starts a CRC, as zlib's crc32
 uint32_t adler32_update(uint32_t adler, const unsigned char *p, size_t n);  // adler32_update(1, ..) starts a sum, as zlib's adler32
 
+// csic_png.cpp: csic_png_write_argb on a given number of threads (<= 0: CSIC_PNG_THREADS or up to 16); the bytes written do
+// not depend on it.  The file pools of csic_files.hip, parallel over files already, ask for 1.
+int png_write_argb_threads(const char *path, const uint32_t *src, int32_t width, int32_t height, int32_t level, int threads);
+
 } // namespace csic

@@ -337,7 +337,9 @@ int  csic_frame_graph_destroy(csic_frame_graph *graph);
  * 8-bit samples as ARGB ints with alpha = 255 (input alpha dropped, gAMA/cHRM not applied -- the behaviour
  * the reference's golden images pin) and writes directly into `dst`, which may be a pinned
  * buffer from csic_pipeline_acquire_input.  Non-interlaced PNGs of every colour type / bit depth are read;
- * 8-bit RGB is written (`level` = zlib level 0..9; at level 1 a frame encodes about four times faster than at 6).
+ * 8-bit RGB is written (`level` = zlib level 0..9; at level 1 a frame encodes about four times faster than at 6),
+ * images of more than 1 MiB of filtered data on up to 16 threads (CSIC_PNG_THREADS=n sets the number; the bytes
+ * written do not depend on it: the deflate stream is cut into pieces by the data alone).
  * The reader accepts and rejects exactly what zlib's inflate does (csrc/csic_inflate.cpp); environment variable
  * CSIC_NO_SIMD=1 keeps it off the PCLMULQDQ / SSSE3 paths it otherwise takes where the CPU has them. */
 int  csic_png_info(const char *path, int32_t *width, int32_t *height);

@@ -260,6 +260,15 @@ int main(int argc, char **argv)
     std::vector<uint32_t> back(37 * 23);
     if (csic_png_read_argb(tmp.c_str(), back.data(), back.size()) != 0) { std::printf("read failed\n"); return 1; }
     for (size_t i = 0; i < img.size(); ++i) if ((img[i] | 0xFF000000u) != back[i]) { std::printf("roundtrip mismatch\n"); return 1; }
+    {   // an image of two deflate pieces (1.26 MB filtered), written on three threads
+        std::vector<uint32_t> big(700 * 600), bigback(700 * 600);
+        for (size_t i = 0; i < big.size(); ++i) big[i] = (i / 700) % 3 ? rnd() : (uint32_t)(i * 2654435761u >> 8);
+        setenv("CSIC_PNG_THREADS", "3", 1);
+        if (csic_png_write_argb(tmp.c_str(), big.data(), 700, 600, 4) != 0) { std::printf("threaded write failed\n"); return 1; }
+        unsetenv("CSIC_PNG_THREADS");
+        if (csic_png_read_argb(tmp.c_str(), bigback.data(), bigback.size()) != 0) { std::printf("read of the threaded file failed\n"); return 1; }
+        for (size_t i = 0; i < big.size(); ++i) if ((big[i] | 0xFF000000u) != bigback[i]) { std::printf("threaded roundtrip mismatch\n"); return 1; }
+    }
     long fuzzed = 0, accepted = 0;
     const std::string mut = std::string(argv[1]) + "/mut.png";
     for (int a = 2; a < argc; ++a) {

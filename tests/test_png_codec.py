@@ -136,6 +136,33 @@ def test_every_sequence_of_row_filters(tmp_path, channels):
             assert np.array_equal(M.readImage(str(p)).rgb(), px[..., :3]), (W, last)
 
 
+def test_large_images_are_written_on_several_threads_with_the_same_bytes(tmp_path, monkeypatch):
+    """The writer filters rows in blocks and deflates the filtered stream in 1 MiB pieces on up to 16 threads; the pieces are
+    defined by the data, so the file must be the same bytes on any thread count -- and a valid PNG for Pillow and for our reader."""
+    rng = np.random.default_rng(9)
+    H, W = 1100, 1500                                              # 4.95 MB filtered: 5 pieces
+    yy, xx = np.mgrid[0:H, 0:W]
+    rgb = np.stack([xx // 3, yy // 2, (xx + yy) // 5], -1).astype(np.uint8)
+    rgb[200:700] ^= rng.integers(0, 32, (500, W, 3), dtype=np.uint8)             # a noisy band, a flat band, smooth elsewhere
+    rgb[800:900] = 77
+    img = csic.Image.from_rgb(rgb)
+    for level in (0, 1, 6):
+        outs = []
+        for threads in ("1", "3", "16"):
+            monkeypatch.setenv("CSIC_PNG_THREADS", threads)
+            p = tmp_path / f"big_{level}_{threads}.png"
+            M.writeImage(img, str(p), compression=level)
+            outs.append(p.read_bytes())
+        assert outs[0] == outs[1] == outs[2], level
+        assert outs[0].count(b"IDAT") >= 5
+        assert np.array_equal(np.asarray(PILImage.open(p).convert("RGB")), rgb)
+        assert np.array_equal(M.readImage(str(p)).rgb(), rgb)
+    monkeypatch.delenv("CSIC_PNG_THREADS")
+    small = csic.Image.from_rgb(rgb[:100, :200])                   # up to 1 MiB filtered: one piece, one IDAT, as ever
+    M.writeImage(small, str(tmp_path / "small.png"))
+    assert (tmp_path / "small.png").read_bytes().count(b"IDAT") == 1
+
+
 def test_every_kind_of_deflate_stream(tmp_path):
     """The reader has its own inflate: IDAT streams of every level, strategy and window size (stored, fixed and dynamic blocks,
     flush points, several IDAT chunks) over noisy, smooth and flat pixels must decode to what Pillow (zlib) decodes."""

@@ -14,7 +14,7 @@ def test_host_code_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "host_sanitize")
     subprocess.check_call(["g++", "-std=c++17", *SAN, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"),
                            os.path.join(ROOT, "tests", "cpp", "host_sanitize.cpp"), os.path.join(PKG, "csrc", "csic_host.cpp"),
-                           os.path.join(PKG, "csrc", "csic_png.cpp"), os.path.join(PKG, "csrc", "csic_inflate.cpp"), os.path.join(PKG, "csrc", "csic_stream.cpp"), "-lz", "-o", exe])
+                           os.path.join(PKG, "csrc", "csic_png.cpp"), os.path.join(PKG, "csrc", "csic_inflate.cpp"), os.path.join(PKG, "csrc", "csic_stream.cpp"), "-lz", "-pthread", "-o", exe])
     files = sorted(glob.glob(os.path.join(GOLDEN, "inputs", "*.png"))) + \
         [os.path.join(GOLDEN, "outputs", n) for n in ("app_422_888_sf2_128.png", "chroma_420_16.png", "old_chroma_420_512.png")]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")

@@ -115,6 +115,27 @@ def main():
         res["png_codec"][os.path.basename(path)] = {
             "size": f"{img.width}x{img.height}", "file_bytes": os.path.getsize(path),
             "decode_Mpixels_per_s": round(npx * reps / bd / 1e6, 1), "encode_Mpixels_per_s": round(npx * reps / be / 1e6, 1)}
+    # ---- the writer on several threads: a cfg 4 result (4096x4096, what 8192x8192 at sf=2 leaves) ---------------------
+    rngw = np.random.default_rng(44)
+    yy, xx = np.mgrid[0:4096, 0:4096]
+    res4 = (0xFF000000 | ((((xx >> 2) & 255) ^ rngw.integers(0, 8, xx.shape, dtype=np.uint32)) << 16) | (((yy >> 1) & 255) << 8) |
+            (((xx + yy) >> 3) & 255)).astype(np.uint32)
+    img4 = csic.Image(res4)
+    p4 = os.path.join(tmp, "cfg4_result.png")
+    wr = {}
+    for label, thr in (("1 thread", "1"), ("library's choice (up to 16)", None)):
+        if thr is None:
+            os.environ.pop("CSIC_PNG_THREADS", None)
+        else:
+            os.environ["CSIC_PNG_THREADS"] = thr
+        for level in (1, 6):
+            b, _ = best_of(lambda: M.writeImage(img4, p4, compression=level), 2)
+            wr[f"level {level}, {label}"] = {"s": round(b, 3), "Mpixels_per_s": round(4096 * 4096 / b / 1e6, 1), "file_bytes": os.path.getsize(p4)}
+    os.environ.pop("CSIC_PNG_THREADS", None)
+    b, _ = best_of(lambda: M.readImage(p4), 2)
+    wr["read back (one thread: a PNG is one zlib stream)"] = {"s": round(b, 3), "Mpixels_per_s": round(4096 * 4096 / b / 1e6, 1)}
+    res["png_writer_threads"] = {"image": "4096x4096 RGB, smooth + 3 bits of noise in one channel (50 MB filtered, 48 deflate pieces)", "runs": wr,
+                                 "note": "same bytes on any thread count (tests/test_png_codec.py)"}
     # ---- cfg 5 end to end FROM FILES: 64 4K PNGs in, 64 PNGs out -------------------------------
     # csic_process_png_files: decoder / encoder thread pools around pinned frame slots.  Frames: a smooth pattern that moves
     # with the frame index plus 3 bits of noise per channel (neither a flat test card nor incompressible noise).
