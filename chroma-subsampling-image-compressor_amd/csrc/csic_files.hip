@@ -14,6 +14,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -21,6 +22,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "csic_hip_common.h"
 
@@ -33,9 +36,33 @@ inline double secs(Clock::time_point a, Clock::time_point b) { return std::chron
 
 struct Slot {
     uint32_t *h_in = nullptr, *h_out = nullptr;
+    void *registered = nullptr;                   // base of the one registered allocation that holds both (else: two hipHostMalloc blocks)
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
 };
+
+// Pinned memory for one slot.  hipHostMalloc pins 4 KiB page by page under a lock: 5.7 ms for a 35 MB slot on an idle host, 49 ms
+// each when 16 threads ask at once, and hipHostFree is no better (77 ms each) -- the decoders of a batch used to wait 0.06-0.1 s
+// for their slots.  Memory that is already there in 2 MiB pages (aligned_alloc + MADV_HUGEPAGE + first touch) registers in
+// 0.1 ms and the whole sequence takes 2.8 ms alone, 30 ms wall for 16 at once (tools/probe_pin.py, profiles/r03_probe_pin.log).
+// Registered memory has the same address on the device (checked), so the kernels take it like hipHostMalloc's.
+constexpr size_t kHugePage = (size_t)2 << 20;
+
+bool register_slot_memory(size_t in_bytes, size_t out_bytes, Slot &s)
+{
+    const size_t in_room = (in_bytes + 4095) & ~(size_t)4095, total = (in_room + out_bytes + kHugePage - 1) & ~(kHugePage - 1);
+    void *p = std::aligned_alloc(kHugePage, total);
+    if (!p) return false;
+    (void)madvise(p, total, MADV_HUGEPAGE);
+    std::memset(p, 0, total);                     // first touch: the pages exist, as huge pages where the host allows, before they are pinned
+    void *d = nullptr;
+    if (hipHostRegister(p, total, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); std::free(p); return false; }
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || d != p) { (void)hipGetLastError(); (void)hipHostUnregister(p); std::free(p); return false; }
+    s.registered = p;
+    s.h_in = static_cast<uint32_t *>(p);
+    s.h_out = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(p) + in_room);
+    return true;
+}
 
 struct Shared {
     csic_plan *plan = nullptr;
@@ -51,8 +78,7 @@ struct Shared {
     std::condition_variable cv_free, cv_work;
     std::deque<int> free_slots;
     int acquired = 0;                             // files whose decoder has got its slot: at n, no slot will be asked for again
-    int created = 0;                              // slots allocated so far (each by the decoder thread that first needed one:
-                                                  // pinning 35 MB takes ~10 ms, 50 slots one after the other were 0.5 s of a 1.2 s batch)
+    int created = 0;                              // slots allocated so far (each by the decoder thread that first needed one)
     std::deque<std::pair<int, int>> inflight;     // (slot, file index), oldest first
     int decoders_running = 0;
     std::atomic<int> next_file{0};
@@ -76,8 +102,11 @@ void fail(Shared &sh, int status, const std::string &msg)
 
 bool make_slot(Shared &sh, Slot &s)
 {
-    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&s.h_in), sh.in_px * 4, hipHostMallocMapped);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_out), sh.out_px * 4, hipHostMallocMapped);
+    hipError_t e = hipSuccess;
+    if (!register_slot_memory(sh.in_px * 4, sh.out_px * 4, s)) {                    // (a host without hipHostRegister: the slower way)
+        e = hipHostMalloc(reinterpret_cast<void **>(&s.h_in), sh.in_px * 4, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&s.h_out), sh.out_px * 4, hipHostMallocMapped);
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -92,8 +121,13 @@ void free_slot(Slot &s)                           // the slot is idle: its event
 {
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.stream) (void)hipStreamDestroy(s.stream);
-    if (s.h_in) (void)hipHostFree(s.h_in);
-    if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.registered) {
+        (void)hipHostUnregister(s.registered);
+        std::free(s.registered);
+    } else {
+        if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.h_out) (void)hipHostFree(s.h_out);
+    }
     s = Slot();
 }
 
