@@ -519,6 +519,31 @@ def test_process_images_thread_pools_write_the_same_bytes_as_the_serial_path(csi
         assert np.array_equal(load_png_rgb(b_out[k]), want), k
 
 
+def test_process_images_pools_with_either_kind_of_pinned_slot(csic, oracle, tmp_path, monkeypatch):
+    """The frame slots are huge-page memory registered with HIP (hipHostRegister); CSIC_FILES_NO_REGISTER=1 selects what a host
+    without it falls back to, hipHostMalloc.  Same files either way."""
+    from PIL import Image as PILImage
+    W, H, n = 128, 64, 9
+    PS = csic.ProcessingStep
+    ins = []
+    for k in range(n):
+        p = tmp_path / f"in{k}.png"
+        PILImage.fromarray(oracle.argb_to_rgb(oracle.synth_frame(W * H, 31 * k + 3).reshape(H, W)), "RGB").save(p)
+        ins.append(str(p))
+    args = (2, 0, 3, 3, 2, 2, PS.ChromaSubsampling, PS.SpatialSampling, PS.ColorQuantization)
+    outs = {}
+    for mode in ("registered", "host_malloc"):
+        if mode == "host_malloc":
+            monkeypatch.setenv("CSIC_FILES_NO_REGISTER", "1")
+        paths = [str(tmp_path / mode / f"o{k}.png") for k in range(n)]
+        st = csic.ImageCompressionApp.processImages(ins, paths, *args, decodeThreads=3, encodeThreads=2)
+        assert st["frames"] == n
+        outs[mode] = [open(p, "rb").read() for p in paths]
+    assert outs["registered"] == outs["host_malloc"]
+    want = oracle.process(_oparams(oracle, W, H, 2, 0, (3, 3, 2), 2), oracle.rgb_to_argb(oracle.argb_to_rgb(oracle.synth_frame(W * H, 3).reshape(H, W))))
+    assert np.array_equal(load_png_rgb(str(tmp_path / "registered" / "o0.png")), oracle.argb_to_rgb(want))
+
+
 def test_process_images_pool_non_divisible_dimensions_and_errors(csic, oracle, tmp_path):
     """Dimensions that do not divide by the factor: the collector keeps the first (W/f)*(H/f) pixels of the ceil-sized output
     stream (ImageCompressorTopApp.scala:44-45,108-124) -- same bytes from both paths.  A file of another size, a missing file
