@@ -15,7 +15,8 @@
 //
 // The reader is what bounds the path from files (profiles/r03_host_io.json), so 8-bit RGB / RGBA -- what the reference's
 // inputs and every encoder's default are -- have their own row loops: the Sub / Average filters carry the previous
-// pixel in registers instead of re-loading the bytes just stored, Paeth works on a whole pixel in one SSE2 register,
+// pixel in registers instead of re-loading the bytes just stored, Paeth works on a whole pixel in one SSE2 register (runs of
+// Average / Paeth rows: two or four rows at a time, skewed by a pixel, so that several dependency chains are in flight),
 // and the conversion to ARGB words is one byte shuffle per four pixels where the CPU has SSSE3.  Everything else
 // (grey, palette, 16-bit, sub-byte depths) takes the plain byte loops.
 #include <zlib.h>
@@ -229,6 +230,47 @@ template <int BPP, int FT0, int FT1> void unfilter_two_rows(unsigned char *cur0,
     store_px<BPP>(cur1 + (npx - 1) * BPP, a1);
 }
 
+// Four rows of ONE filter type, two to a register: rows 0 | 1 in the halves of A, rows 2 | 3 in B, row r at pixel x - r.  One
+// filter_step then serves two rows, and the two registers are two chains in flight: the arithmetic of four pixels in the time the
+// chain of one takes.  A row's "above" is the row before it one step earlier -- the other half of the register, or the other
+// register -- and its "above left" is the "above" of the step before.  Rows that have not started yet are kept at zero (what
+// lies left of the image); rows that have ended feed only rows that have ended too.
+template <int BPP, int FT> void unfilter_four_rows(unsigned char *const cur[4], const unsigned char *prev, size_t npx)
+{
+    const __m128i zero = _mm_setzero_si128();
+    const __m128i lo_half = _mm_set_epi64x(0, -1);
+    auto load2 = [&](const unsigned char *p, const unsigned char *q) {
+        uint32_t a, b;
+        std::memcpy(&a, p, 4); std::memcpy(&b, q, 4);
+        return _mm_unpacklo_epi8(_mm_unpacklo_epi32(_mm_cvtsi32_si128((int)a), _mm_cvtsi32_si128((int)b)), zero);
+    };
+    auto store = [&](int r, ptrdiff_t x, uint32_t v) { if (x >= 0 && x < (ptrdiff_t)npx) std::memcpy(cur[r] + x * BPP, &v, BPP); };
+    __m128i A = zero, B = zero, cA = zero, cB = zero;
+    const ptrdiff_t n = (ptrdiff_t)npx;
+    for (ptrdiff_t i = 0; i < n + 3; ++i) {
+        const __m128i rA = load2(cur[0] + i * BPP, cur[1] + (i - 1) * BPP), rB = load2(cur[2] + (i - 2) * BPP, cur[3] + (i - 3) * BPP);
+        const __m128i bA = _mm_unpacklo_epi64(load_px(prev + i * BPP), A);                                   // [ row above | row 0 one step ago ]
+        const __m128i bB = _mm_castpd_si128(_mm_shuffle_pd(_mm_castsi128_pd(A), _mm_castsi128_pd(B), 1));   // [ row 1 | row 2 ], one step ago
+        __m128i nA = filter_step<FT>(rA, A, bA, cA), nB = filter_step<FT>(rB, B, bB, cB);
+        if (i < 3) {                                                                                          // rows 1..3 start one step apart
+            if (i == 0) { nA = _mm_and_si128(nA, lo_half); nB = zero; }
+            else if (i == 1) nB = zero;
+            else nB = _mm_and_si128(nB, lo_half);
+        }
+        cA = bA; cB = bB; A = nA; B = nB;
+        const __m128i pa = _mm_packus_epi16(nA, nA), pb = _mm_packus_epi16(nB, nB);
+        if (i >= 3 && i < n) {                                                                                // all four rows inside the image
+            const uint32_t v0 = (uint32_t)_mm_cvtsi128_si32(pa), v1 = (uint32_t)_mm_cvtsi128_si32(_mm_srli_si128(pa, 4));
+            const uint32_t v2 = (uint32_t)_mm_cvtsi128_si32(pb), v3 = (uint32_t)_mm_cvtsi128_si32(_mm_srli_si128(pb, 4));
+            std::memcpy(cur[0] + i * BPP, &v0, BPP); std::memcpy(cur[1] + (i - 1) * BPP, &v1, BPP);
+            std::memcpy(cur[2] + (i - 2) * BPP, &v2, BPP); std::memcpy(cur[3] + (i - 3) * BPP, &v3, BPP);
+        } else {
+            store(0, i, (uint32_t)_mm_cvtsi128_si32(pa)); store(1, i - 1, (uint32_t)_mm_cvtsi128_si32(_mm_srli_si128(pa, 4)));
+            store(2, i - 2, (uint32_t)_mm_cvtsi128_si32(pb)); store(3, i - 3, (uint32_t)_mm_cvtsi128_si32(_mm_srli_si128(pb, 4)));
+        }
+    }
+}
+
 template <int BPP> void unfilter_two_rows(int ft0, int ft1, unsigned char *cur0, unsigned char *cur1, const unsigned char *prev, size_t npx)
 {
     if (ft0 == 3) { if (ft1 == 3) unfilter_two_rows<BPP, 3, 3>(cur0, cur1, prev, npx); else unfilter_two_rows<BPP, 3, 4>(cur0, cur1, prev, npx); }
@@ -253,6 +295,13 @@ template <int BPP> int decode_rows_8bit(const char *path, unsigned char *raw, si
         const unsigned char *prev = y ? cur - (stride + 1) : zero_row;
         const int ft = cur[-1];
 #if defined(__x86_64__)
+        if ((ft == 3 || ft == 4) && y + 3 < H && W >= 4 && cur[stride] == ft && cur[2 * stride + 1] == ft && cur[3 * stride + 2] == ft) {
+            unsigned char *const rows[4] = {cur, cur + (stride + 1), cur + 2 * (stride + 1), cur + 3 * (stride + 1)};   // (filter bytes of the next three rows)
+            if (ft == 3) unfilter_four_rows<BPP, 3>(rows, prev, W); else unfilter_four_rows<BPP, 4>(rows, prev, W);
+            for (int r = 0; r < 4; ++r) emit(rows[r], y + (size_t)r);
+            y += 3;
+            continue;
+        }
         if ((ft == 3 || ft == 4) && y + 1 < H && (cur[stride] == 3 || cur[stride] == 4)) {       // cur[stride]: the next row's filter byte
             unfilter_two_rows<BPP>(ft, cur[stride], cur, cur + stride + 1, prev, W);
             emit(cur, y);

@@ -128,6 +128,14 @@ def test_every_sequence_of_row_filters(tmp_path, channels):
             want = np.asarray(PILImage.open(p).convert("RGB"))
             assert np.array_equal(want, px[..., :3])
             assert np.array_equal(M.readImage(str(p)).rgb(), want), (W, shift)
+        for filters in ([3] * 9 + [4] * 9 + [3, 3, 3, 3, 4, 4, 4, 4, 3], [4] * 13 + [2] + [3] * 6):      # runs: four rows at a time, then two, then one
+            H = len(filters)
+            px = rng.integers(0, 256, (H, W, channels), dtype=np.uint8)
+            px[H // 2:] = (np.arange(W)[None, :, None] * 5 + np.arange(H - H // 2)[:, None, None] * 2).astype(np.uint8)
+            p = tmp_path / f"r{W}_{len(filters)}.png"
+            p.write_bytes(_png_with_filters(px, filters))
+            assert np.array_equal(np.asarray(PILImage.open(p).convert("RGB")), px[..., :3])
+            assert np.array_equal(M.readImage(str(p)).rgb(), px[..., :3]), (W, filters)
         for last in (3, 4):                                                       # an odd row count ending in a lone Average / Paeth row
             filters = [4, 3, last]
             px = rng.integers(0, 256, (3, W, channels), dtype=np.uint8)
