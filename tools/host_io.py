@@ -136,6 +136,29 @@ def main():
     wr["read back (one thread: a PNG is one zlib stream)"] = {"s": round(b, 3), "Mpixels_per_s": round(4096 * 4096 / b / 1e6, 1)}
     res["png_writer_threads"] = {"image": "4096x4096 RGB, smooth + 3 bits of noise in one channel (50 MB filtered, 48 deflate pieces)", "runs": wr,
                                  "note": "same bytes on any thread count (tests/test_png_codec.py)"}
+    # ---- cfg 4 end to end from ONE file: the reference's actual flow (ImageCompressionApp.processImage) on the headline frame -------
+    yy, xx = np.mgrid[0:8192, 0:8192]
+    big = (0xFF000000 | ((((xx >> 3) & 255) ^ rngw.integers(0, 8, xx.shape, dtype=np.uint32)) << 16) | (((yy >> 2) & 255) << 8) |
+           (((xx + yy) >> 4) & 255)).astype(np.uint32)
+    p8 = os.path.join(tmp, "cfg4_input.png")
+    M.writeImage(csic.Image(big), p8)
+    del big, yy, xx
+    PS4 = csic.ProcessingStep
+    a4 = (2, 0, 8, 8, 8, 2, PS4.ChromaSubsampling, PS4.SpatialSampling, PS4.ColorQuantization)
+    o4 = os.path.join(tmp, "cfg4_output.png")
+    one = {}
+    for label, thr in (("writer on 1 thread", "1"), ("writer on the library's choice of threads", None)):
+        if thr is None:
+            os.environ.pop("CSIC_PNG_THREADS", None)
+        else:
+            os.environ["CSIC_PNG_THREADS"] = thr
+        b, _ = best_of(lambda: csic.ImageCompressionApp.processImage(p8, o4, *a4), 2)
+        one[label] = {"s": round(b, 3), "Mpixels_per_s": round(8192 * 8192 / b / 1e6, 1)}
+    os.environ.pop("CSIC_PNG_THREADS", None)
+    b, _ = best_of(lambda: M.readImage(p8), 2)
+    one["of which: reading the 8192x8192 PNG (one thread)"] = {"s": round(b, 3), "file_bytes": os.path.getsize(p8)}
+    res["cfg4_from_one_file"] = {"workload": "ImageCompressionApp.processImage: one 8192x8192 PNG -> 4:2:0, sf=2, 8/8/8 bits -> one 4096x4096 PNG (level 6); "
+                                             "the kernel's share is 32 us", "runs": one}
     # ---- cfg 5 end to end FROM FILES: 64 4K PNGs in, 64 PNGs out -------------------------------
     # csic_process_png_files: decoder / encoder thread pools around pinned frame slots.  Frames: a smooth pattern that moves
     # with the frame index plus 3 bits of noise per channel (neither a flat test card nor incompressible noise).
