@@ -123,7 +123,26 @@ def cpu_baseline(W, H, a, b, bits, f, budget_s=10.0):
         else "no JVM on this host (`java` not found): the Scala/JVM CPU path is not measured and not substituted"
     res["all_cores"] = {"value": round(m * W * H / el2 / 1e6, 1), "unit": "Mpixels/s", "cores": ncores,
                         "sample": f"{m} frames, orc_process_closed_mt on {ncores} threads in {el2:.1f} s"}
+    quota = cpu_quota_cores()
+    if quota is not None:                                        # a container may see 256 CPUs and be allowed the time of 16
+        res["all_cores"]["cpu_quota_cores"] = quota
+        res["all_cores"]["sample"] += f"; the cgroup grants this job the CPU time of {quota:g} cores (cpu.max)"
     return res
+
+
+def cpu_quota_cores():
+    """CPU time the cgroup allows per period, in cores (cgroup v2 cpu.max, v1 cfs quota); None when unlimited or unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except (OSError, ValueError):
+        return None
 
 
 def load_traffic(config, kernel_name, world):

@@ -24,6 +24,15 @@ import torch  # noqa: E402
 import csic_amd as csic  # noqa: E402
 
 
+def cpu_quota_cores():
+    """CPU time the cgroup allows this job, in cores (cpu.max); None when unlimited.  The GPU boxes show 256 CPUs and grant 16."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        return None
+
+
 def best_of(fn, n=5):
     fn()
     ts = []
@@ -218,7 +227,7 @@ def main():
     res["cfg5_from_files"] = {
         "workload": f"{n5} PNG files of {W5}x{H5} ({in_bytes / 1e6:.0f} MB on disk) -> 4:2:0, sf=4, Y3Cb3Cr2 -> {n5} PNG files of {W5 // 4}x{H5 // 4}; "
                     "wall clock of ImageCompressionApp.processImages including plan creation and slot allocation",
-        "host_cores_available": ncpu, "runs": runs,
+        "host_cores_available": ncpu, "cpu_quota_cores": cpu_quota_cores(), "runs": runs,
         "best": {k: best_run[k] for k in ("decode_threads", "encode_threads", "wall_s", "Mpixels_per_s", "cores_used", "bound_by")},
         "speedup_over_serial": round(best_run["Mpixels_per_s"] / runs[0]["Mpixels_per_s"], 1),
         "note": "input pixels per second; the kernel's share is microseconds per frame (cfg 5: 1.7 us), PCIe moves one row in four (sf=4)"}

@@ -24,7 +24,7 @@ for k in range(n):
     ins.append(p)
 outs = [os.path.join(tmp, "out", f"o{k:02d}.png") for k in range(n)]
 args = (2, 0, 3, 3, 2, 4, PS.ChromaSubsampling, PS.SpatialSampling, PS.ColorQuantization)
-for D, E in ((None, None), (32, 16), (64, 16), (64, 32), (48, 16)):
+for D, E in ((None, None), (12, 4), (16, 8), (24, 8), (24, 12), (32, 16), (48, 16)):
     for rep in range(3):
         t0 = time.perf_counter()
         st = csic.ImageCompressionApp.processImages(ins, outs, *args, decodeThreads=D, encodeThreads=E)
