@@ -60,10 +60,17 @@ CONFIGS = {
     "sq1000": (1000, 1000, 2, 0, (8, 8, 8), 8, 1),
     "sq1024": (1024, 1024, 2, 0, (8, 8, 8), 8, 1),
 }
-# AVG sampling extension (no reference counterpart): same shapes as cfg4 / cfg5, every input row is live
-AVG_CONFIGS = {"avg_8k_420_sf2": "cfg4", "avg_4k_420_sf4": "cfg5"}
-for _k, _v in AVG_CONFIGS.items():
-    CONFIGS[_k] = CONFIGS[_v]
+# AVG sampling extension (no reference counterpart): same shapes as cfg4 / cfg5, every input row is live; the ragged shapes
+# (W % 4 != 0 or H % max(f, v) != 0: 1366x768 at sf 4, 1001x1001 at sf 8) sit next to their nearest aligned neighbours
+AVG_CONFIGS = {"avg_8k_420_sf2": CONFIGS["cfg4"], "avg_4k_420_sf4": CONFIGS["cfg5"],
+               "avg_1366x768_sf4": (1366, 768, 2, 0, (8, 8, 8), 4, 1), "avg_1368x768_sf4": (1368, 768, 2, 0, (8, 8, 8), 4, 1),
+               "avg_1001_sf8": (1001, 1001, 2, 0, (8, 8, 8), 8, 1), "avg_1000_sf8": (1000, 1000, 2, 0, (8, 8, 8), 8, 1),
+               "avg_1922x1082_sf2": (1922, 1082, 2, 0, (8, 8, 8), 2, 1), "avg_1920x1080_sf2": (1920, 1080, 2, 0, (8, 8, 8), 2, 1)}
+CONFIGS.update(AVG_CONFIGS)
+# planar output (CSIC_FMT_PLANAR: Y plane + Cb / Cr planes at the chroma sample points only; the reconstruct kernel beside it)
+PLANAR_CONFIGS = {"planar_8k_420_f1": CONFIGS["8k_420_f1"], "planar_8k_420_f1_avg": CONFIGS["8k_420_f1"],
+                  "planar_cfg4": CONFIGS["cfg4"]}
+CONFIGS.update(PLANAR_CONFIGS)
 CSQ = (3, 1, 2)
 # launches per step (--batch-frames 0): the headline config times batches of frames, each frame its own launch, so that the
 # K = 20 steps the driver asks for are milliseconds of GPU work at every N; the others stay at one launch per step
@@ -74,22 +81,26 @@ SCQ = (1, 3, 2)            # spatial before chroma (the reference app's default 
 FALLBACK = {"direct": "hip", "hip": "serial", "fused": "serial"}
 
 
-def cpu_baseline(W, H, a, b, bits, f, budget_s=10.0):
+def cpu_baseline(W, H, a, b, bits, f, budget_s=10.0, order=CSQ, avg=False, keep=None):
     """The oracle's streaming restatement (oracle/csic_oracle.c, scalar C, 1 thread) timed on this
-    host on whole frames of the same workload until ~budget_s of CPU work has been done."""
+    host on whole frames of the same workload until ~budget_s of CPU work has been done.  `keep` (a dict) receives the
+    oracle's output for frame 0 -- the checker's half of the line's `verified` object."""
     import numpy as np
     from oracle import oracle as orc
     orc.build()
     p = orc.OracleParams(width=W, height=H, chroma_a=a, chroma_b=b, y_bits=bits[0], cb_bits=bits[1],
-                         cr_bits=bits[2], factor=f, op=CSQ)
+                         cr_bits=bits[2], factor=f, op=tuple(order))
     frame = orc.synth_frame(W * H, 0)
     wo, ho = orc.out_dims(p)
     out = np.empty(wo * ho, dtype=np.uint32)
     cp = p.c()
-    fn = orc.lib().orc_process_stream
+    fn = orc.lib().orc_process_avg if avg else orc.lib().orc_process_stream
+    fn_name = "orc_process_avg (the AVG extension's own normative form)" if avg else "orc_process_stream"
     u32p = C.POINTER(C.c_uint32)
     pin, pout = frame.ctypes.data_as(u32p), out.ctypes.data_as(u32p)
     fn(C.byref(cp), pin, pout)                                   # warm-up (page faults)
+    if keep is not None:
+        keep["out"], keep["form"] = out.copy(), fn_name.split(" ")[0]
     n, t0 = 0, time.perf_counter()
     while True:
         fn(C.byref(cp), pin, pout)
@@ -99,7 +110,7 @@ def cpu_baseline(W, H, a, b, bits, f, budget_s=10.0):
             break
     res = {
         "value": round(n * W * H / el / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-        "sample": f"{n} full {W}x{H} frames through oracle/csic_oracle.c orc_process_stream "
+        "sample": f"{n} full {W}x{H} frames through oracle/csic_oracle.c {fn_name} "
                   f"(scalar C -O2, streaming state machines) in {el:.1f} s; host has {os.cpu_count()} logical cores",
     }
     # BASELINE.md "CPU baseline B": the same restatement (closed form) row-parallel on the cores this
@@ -109,24 +120,94 @@ def cpu_baseline(W, H, a, b, bits, f, budget_s=10.0):
     except AttributeError:
         ncores = os.cpu_count() or 1
     ncores = max(1, min(ncores, 256))
-    fmt = orc.lib().orc_process_closed_mt
-    fmt(C.byref(cp), pin, pout, ncores)
-    m, t0 = 0, time.perf_counter()
-    while True:
+    res["jvm"] = jvm_baseline(W, H, a, b, bits, f, order, min(budget_s, 8.0), want_out=out) if not avg else \
+        "the Scala/JVM model has no AVG extension (the reference has none)"
+    if not avg:
+        fmt = orc.lib().orc_process_closed_mt
         fmt(C.byref(cp), pin, pout, ncores)
-        m += 1
-        el2 = time.perf_counter() - t0
-        if el2 >= min(budget_s, 5.0) or m >= 256:
-            break
+        m, t0 = 0, time.perf_counter()
+        while True:
+            fmt(C.byref(cp), pin, pout, ncores)
+            m += 1
+            el2 = time.perf_counter() - t0
+            if el2 >= min(budget_s, 5.0) or m >= 256:
+                break
+        res["all_cores"] = {"value": round(m * W * H / el2 / 1e6, 1), "unit": "Mpixels/s", "cores": ncores,
+                            "sample": f"{m} frames, orc_process_closed_mt on {ncores} threads in {el2:.1f} s"}
+        quota = cpu_quota_cores()
+        if quota is not None:                                    # a container may see 256 CPUs and be allowed the time of 16
+            res["all_cores"]["cpu_quota_cores"] = quota
+            res["all_cores"]["sample"] += f"; the cgroup grants this job the CPU time of {quota:g} cores (cpu.max)"
+    return res
+
+
+JAVA_BENCH = os.path.join(ROOT, "chroma-subsampling-image-compressor_amd", "jvm", "java", "SoftwareModelBench.java")
+
+
+def frame_checksum(px):
+    """csic_checksum_device's sum on the host: sum_i fmix32(px[i] + 0x9E3779B9 * i), 64-bit (numpy, uint32 wrap-around)."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        x = px.astype(np.uint32) + np.uint32(0x9E3779B9) * np.arange(px.size, dtype=np.uint32)
+        x ^= x >> np.uint32(16); x *= np.uint32(0x85ebca6b); x ^= x >> np.uint32(13); x *= np.uint32(0xc2b2ae35); x ^= x >> np.uint32(16)
+    return int(x.astype(np.uint64).sum()) & 0xFFFFFFFFFFFFFFFF
+
+
+def jvm_baseline(W, H, a, b, bits, f, order, budget_s, want_out=None):
+    """The north star's "reference Scala/JVM CPU path": jvm/java/SoftwareModelBench.java is the Array[Int] algorithm of
+    jvm/scala/jpeg/SoftwareModel.scala as ONE source file, which a JDK >= 11 runs without a compiler step
+    (`java SoftwareModelBench.java ...`, JEP 330).  Timed only where `java` exists; otherwise the line says so -- never
+    substituted by anything else."""
     import shutil
-    res["jvm"] = ("java found at %s, but no Scala compiler/model is shipped to time" % shutil.which("java")) if shutil.which("java") \
-        else "no JVM on this host (`java` not found): the Scala/JVM CPU path is not measured and not substituted"
-    res["all_cores"] = {"value": round(m * W * H / el2 / 1e6, 1), "unit": "Mpixels/s", "cores": ncores,
-                        "sample": f"{m} frames, orc_process_closed_mt on {ncores} threads in {el2:.1f} s"}
-    quota = cpu_quota_cores()
-    if quota is not None:                                        # a container may see 256 CPUs and be allowed the time of 16
-        res["all_cores"]["cpu_quota_cores"] = quota
-        res["all_cores"]["sample"] += f"; the cgroup grants this job the CPU time of {quota:g} cores (cpu.max)"
+    import subprocess
+    java = shutil.which("java")
+    if not java:
+        return "no JVM on this host (`java` not found): the Scala/JVM CPU path is not measured and not substituted"
+    cmd = [java, "-Xmx6g", JAVA_BENCH, str(W), str(H), str(a), str(b), str(bits[0]), str(bits[1]), str(bits[2]), str(f),
+           ",".join(str(o) for o in order), f"{budget_s:g}"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s * 6 + 120)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"unavailable": f"`{' '.join(cmd[:3])} ...` exited {r.returncode}: {(r.stderr or r.stdout).strip()[-300:]}"}
+        obj = json.loads(line[-1])
+        obj["kind"] = "jvm port (jvm/java/SoftwareModelBench.java: the algorithm of jvm/scala/jpeg/SoftwareModel.scala, single thread)"
+        obj["java"] = java
+        if want_out is not None and "checksum" in obj:              # the JVM's output frame against the oracle's, by checksum
+            obj["equals_oracle"] = int(obj["checksum"], 16) == frame_checksum(want_out.reshape(-1))
+        return obj
+    except Exception as exc:                                      # noqa: BLE001 -- a reported baseline, never fatal
+        return {"unavailable": f"{type(exc).__name__}: {exc}"}
+
+
+def verify_against_oracle(wl, order, avg, keep, torch):
+    """The line's `verified` object (rank 0, untimed, after the timed region): the GPU's output for the FIRST frame of ring
+    slot 0 -- written by the timed launches themselves -- against the oracle's output for the same frame.  The oracle's
+    half comes from the cpu_baseline leg when that ran (keep["out"]: the streaming form), else from the closed form on
+    all cores.  Rank 0's slot 0 holds the frame that starts at counter 0 (row0 = 0), stripe_rows tall."""
+    import numpy as np
+    from oracle import oracle as orc
+    W, H, a, b, bits, f, _ = CONFIGS[wl.args.config]
+    rows = wl.stripe_rows
+    if wl.pad or wl.row0 != 0 or getattr(wl, "planar", False):
+        return {"vs": "oracle", "frames": 0, "equal": None, "skipped": "padded rows / a stripe that does not start at row 0 / planar output"}
+    got = wl.outs[0][:wl.out_px].cpu().numpy().view(np.uint32)
+    if keep and keep.get("out") is not None and rows == H:
+        want, form = keep["out"], keep["form"]
+    else:
+        orc.build()
+        p = orc.OracleParams(width=W, height=rows, chroma_a=a, chroma_b=b, y_bits=bits[0], cb_bits=bits[1], cr_bits=bits[2],
+                             factor=f, op=tuple(order))
+        frame = orc.synth_frame(W * rows, 0)
+        if avg:
+            want, form = orc.process(p, frame, form="avg").reshape(-1), "orc_process_avg"
+        else:
+            want, form = orc.process_mt(p, frame, min(16, os.cpu_count() or 1)).reshape(-1), "orc_process_closed_mt"
+    equal = bool(got.shape == want.reshape(-1).shape and np.array_equal(got, want.reshape(-1)))
+    res = {"vs": f"oracle ({form})", "frames": 1, "equal": equal, "pixels": int(got.size),
+           "what": f"ring slot 0 as the timed launches left it ({W}x{rows} -> {wl.plan.out_width}x{wl.plan.out_height}), rank 0, untimed"}
+    if not equal:
+        res["mismatching_pixels"] = int((got != want.reshape(-1)).sum()) if got.shape == want.reshape(-1).shape else -1
     return res
 
 
@@ -370,7 +451,8 @@ class Workload:
             def step(i):
                 return lib.csic_process_pitched_device(ph, in_ptrs[i % nring], ip, out_ptrs[i % nring], op, 1, sh)
         elif fps == 1:
-            self.launch_desc = "one launch per step (csic_process_device), eager, one stream"
+            self.launch_desc = (f"one launch per frame (csic_process_device), {args.batch} per step, eager, one stream" if args.batch > 1 else
+                                "one launch per frame = per step (csic_process_device), eager, one stream")
 
             def step(i):
                 return lib.csic_process_device(ph, in_ptrs[i % nring], out_ptrs[i % nring], sh)
@@ -675,6 +757,12 @@ def main(argv=None):
                     help="N=1: skip the `sustained` leg (the headline launches replayed in bursts for as long as the CPU baseline "
                          "runs on its host thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the `verified` object (ring slot 0's output, as the timed launches left it, against the oracle; rank 0, untimed)")
+    ap.add_argument("--no-same-mechanism", action="store_true",
+                    help="N=1: skip the `hip_streams` / `direct_dispatch` side objects -- the full frame through the issue modes the N = 2 and "
+                         "N = 4 / 8 runs use, so that a scaling efficiency can be formed against the SAME mechanism.  They are also skipped "
+                         "under rocprofv3 (their overlapping launches would distort the per-kernel average the roofline is checked against)")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = top.parse_args(argv)
     args.batch = args.batch_frames if args.batch_frames > 0 else \
@@ -835,12 +923,15 @@ def main(argv=None):
 
     # ---- CPU baseline (rank 0, N = 1) on a host thread, the GPU replaying the headline launches meanwhile ---------------
     cpu_res, sustained = None, None
+    keep = {}
+    order_ops = SCQ if args.order == "scq" else CSQ
+    is_avg = args.config in AVG_CONFIGS or args.config.endswith("_avg")
     if world == 1 and not args.no_cpu_baseline:
         box = {}
 
         def cpu_leg():
             try:
-                box["res"] = cpu_baseline(W, H, a, b, bits, f, args.cpu_budget)
+                box["res"] = cpu_baseline(W, H, a, b, bits, f, args.cpu_budget, order=order_ops, avg=is_avg, keep=keep)
             except Exception as exc:                               # noqa: BLE001 -- reported in the object, never fatal
                 box["res"] = {"unavailable": f"{type(exc).__name__}: {exc}"}
 
@@ -877,6 +968,14 @@ def main(argv=None):
                 sustained = {"unavailable": f"{type(exc).__name__}: {exc}"}
         th.join()
         cpu_res = box.get("res")
+    # ---- the line checks its own output (rank 0, untimed, local: no collective) -----------------------------------------
+    verified = None
+    if rank == 0 and not args.no_verify:
+        try:
+            verified = verify_against_oracle(wl, order_ops, is_avg, keep, torch)
+        except Exception as exc:                                   # noqa: BLE001 -- reported, never fatal for the measurement
+            verified = {"vs": "oracle", "frames": 0, "equal": None, "unavailable": f"{type(exc).__name__}: {exc}"}
+    keep.clear()
     wl.close()
 
     def side(scaling, how):
@@ -942,6 +1041,24 @@ def main(argv=None):
         safe_side("serial_launches", headline_mode, "serial")
     elif args.direct and can_graph and issue != "direct":
         safe_side("direct_dispatch", headline_mode, "direct")
+    profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if world == 1 and args.stripe_of <= 1 and args.config == "cfg4" and can_graph and issue == "serial" and args.batch > 1 \
+            and not args.pitch_pad and not args.no_same_mechanism and not args.busy_streams:
+        # Like for like across N: `value` at N = 2 comes from hipGraph chains and at N = 4 / 8 from direct dispatch (see --issue);
+        # the SAME full frame through those two mechanisms here, so that efficiency(N) = value(N) / (N * <this>) compares one
+        # mechanism with itself instead of mixing launch engines.  Never `value`.
+        if profiled:
+            for key in ("hip_streams", "direct_dispatch"):
+                sides.setdefault(key, {"skipped": "under rocprofv3: overlapping launches of the same kernel would distort the per-kernel "
+                                                  "average that the roofline figure is checked against"})
+        else:
+            if "hip_streams" not in sides:
+                safe_side("hip_streams", headline_mode, "hip")
+            if "direct_dispatch" not in sides:
+                safe_side("direct_dispatch", headline_mode, "direct")
+        for key, nn in (("hip_streams", "N = 2"), ("direct_dispatch", "N = 4 and N = 8")):
+            if isinstance(sides.get(key), dict):
+                sides[key]["same_mechanism_as"] = f"`value` at {nn}"
 
 
     def emit():
@@ -961,6 +1078,7 @@ def main(argv=None):
             "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / K, 5),
             "ms_per_launch": round(elapsed * 1e3 / KL / head["launches_per_replay"], 5),
+            "output_mpixels_per_s": round(value * head["out_px"] / max(head["in_px"], 1), 1),
             "higher_is_better": True, "scaling": headline_mode, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {
@@ -1014,6 +1132,8 @@ def main(argv=None):
             line["sustained"] = sustained
         if cpu_res is not None:
             line["cpu_baseline"] = cpu_res
+        if verified is not None:
+            line["verified"] = verified
         print(json.dumps(line), flush=True)
 
     if want_halo:
@@ -1036,6 +1156,10 @@ def main(argv=None):
 
     if pg:
         dist.destroy_process_group()
+    if verified is not None and verified.get("equal") is False:
+        # the timed kernel did not produce the reference's pixels: the number above is not a measurement of the path
+        sys.stderr.write("bench.py: VERIFICATION FAILED -- ring slot 0 differs from the oracle: %s\n" % json.dumps(verified))
+        sys.exit(3)
 
 
 def halo_exchange(args, csic, torch, dist, comm, dev, dev_index, world, rank):

@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsic_hip.so")
+# CSIC_LIB=<path> loads another build of the SAME sources instead -- the range-checking debug build (`make -C csrc debug` ->
+# libcsic_hip_debug.so: every global access of the pixel kernels is checked against the frame extent and traps); nothing else.
+LIB_PATH = os.environ.get("CSIC_LIB") or os.path.join(_HERE, "libcsic_hip.so")
 
 # csic_status (include/csic.h)
 OK = 0
@@ -18,7 +20,7 @@ EIO, EFORMAT = -30, -31
 
 OP_NOOP, OP_SPATIAL, OP_QUANT, OP_CHROMA = 0, 1, 2, 3
 ROUND_FLOOR_HW, ROUND_TRUNC_SW = 0, 1
-FMT_ARGB8888, FMT_YCBCR888X = 0, 1
+FMT_ARGB8888, FMT_YCBCR888X, FMT_PLANAR = 0, 1, 2
 TUNE_VARIANT, TUNE_FORCE_GENERIC, TUNE_NONTEMPORAL, TUNE_NO_VECTOR, TUNE_BLOCK_THREADS = 1, 2, 3, 4, 5
 FRAME_GRAPH_HIP, FRAME_GRAPH_DIRECT, FRAME_GRAPH_FUSED, FRAME_GRAPH_AUTO = 0, 1, 2, 3
 FRAME_GRAPH_DEFAULT_BRANCHES, FRAME_GRAPH_DEFAULT_QUEUES = 4, 3
@@ -64,6 +66,13 @@ class CsicParams(C.Structure):
     ]
 
 
+class CsicPlanarLayout(C.Structure):
+    _fields_ = [("y_width", C.c_int32), ("y_height", C.c_int32), ("chroma_width", C.c_int32), ("chroma_height", C.c_int32),
+                ("module_width", C.c_int32), ("hold_h", C.c_int32), ("hold_v", C.c_int32), ("replay_last", C.c_int32),
+                ("chroma_samples", C.c_int64), ("y_offset", C.c_int64), ("cb_offset", C.c_int64), ("cr_offset", C.c_int64),
+                ("frame_bytes", C.c_int64), ("payload_bytes", C.c_int64)]
+
+
 class CsicFilesStats(C.Structure):
     _fields_ = [("frames", C.c_int64), ("wall_s", C.c_double), ("decode_s", C.c_double), ("encode_s", C.c_double),
                 ("gpu_wait_s", C.c_double), ("slot_wait_s", C.c_double), ("decode_threads", C.c_int32), ("encode_threads", C.c_int32),
@@ -89,6 +98,9 @@ PROTOTYPES = {
     "csic_algorithmic_bytes": (C.c_int, [C.POINTER(CsicParams), C.POINTER(C.c_int64)]),
     "csic_stripe_rows": (C.c_int, [C.POINTER(CsicParams), C.c_int32, C.c_int32] + [C.POINTER(C.c_int32)] * 4),
     "csic_stripe_halo": (C.c_int, [C.POINTER(CsicParams), C.c_int32, C.c_int32, C.POINTER(C.c_int32)] + [C.POINTER(C.c_int32)] * 6),
+    "csic_planar_layout_of": (C.c_int, [C.POINTER(CsicParams), C.POINTER(CsicPlanarLayout)]),
+    "csic_reconstruct_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "csic_plan_preferred_pitch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "csic_strerror": (C.c_char_p, [C.c_int]),
     "csic_last_error": (C.c_char_p, []),
     "csic_device_count": (C.c_int, []),

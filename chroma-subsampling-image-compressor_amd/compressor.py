@@ -70,6 +70,24 @@ class Plan:
     def tune(self, knob: int, value: int) -> None:
         N.check(N.lib().csic_plan_tune(self._h, knob, value))
 
+    @property
+    def planar(self) -> bool:
+        return self.c_params.out_format == N.FMT_PLANAR
+
+    @property
+    def planar_layout(self) -> N.CsicPlanarLayout:
+        """csic_planar_layout of these parameters (whatever the plan's out_format is)."""
+        lay = N.CsicPlanarLayout()
+        N.check(N.lib().csic_planar_layout_of(C.byref(self.c_params), C.byref(lay)))
+        return lay
+
+    @property
+    def preferred_pitch(self) -> Tuple[int, int]:
+        """(in_pitch_px, out_pitch_px) at which a caller that owns its surfaces should lay frames out (csic_plan_preferred_pitch)."""
+        ip, op = C.c_int32(), C.c_int32()
+        N.check(N.lib().csic_plan_preferred_pitch(self._h, C.byref(ip), C.byref(op)))
+        return ip.value, op.value
+
     # -- compute ----------------------------------------------------------------------------------
     def _stream(self):
         import torch
@@ -85,12 +103,20 @@ class Plan:
             raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: tensor is on a different device than the plan")
         if d_in.numel() != nframes * self.width * self.height:
             raise N.IllegalArgumentException(N.EINVAL_SIZE, f"requirement failed: expected {nframes * self.width * self.height} input pixels, got {d_in.numel()}")
-        shape = (self.out_height, self.out_width) if nframes == 1 else (nframes, self.out_height, self.out_width)
-        if d_out is None:
-            d_out = torch.empty(shape, dtype=d_in.dtype, device=d_in.device)
-        elif d_out.numel() != nframes * self.out_width * self.out_height or not d_out.is_contiguous() \
-                or d_out.element_size() != 4 or d_out.device != d_in.device:
-            raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: d_out has the wrong size/layout")
+        if self.planar:
+            # planar frame buffers: frame_bytes bytes per frame (csic_planar_layout), a uint8 tensor (nframes, frame_bytes)
+            fb = self.planar_layout.frame_bytes
+            if d_out is None:
+                d_out = torch.empty((nframes, fb) if nframes > 1 else (fb,), dtype=torch.uint8, device=d_in.device)
+            elif d_out.numel() * d_out.element_size() != nframes * fb or not d_out.is_contiguous() or d_out.device != d_in.device:
+                raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: d_out must hold nframes * planar_layout.frame_bytes bytes")
+        else:
+            shape = (self.out_height, self.out_width) if nframes == 1 else (nframes, self.out_height, self.out_width)
+            if d_out is None:
+                d_out = torch.empty(shape, dtype=d_in.dtype, device=d_in.device)
+            elif d_out.numel() != nframes * self.out_width * self.out_height or not d_out.is_contiguous() \
+                    or d_out.element_size() != 4 or d_out.device != d_in.device:
+                raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: d_out has the wrong size/layout")
         if nframes == 1:
             st = N.lib().csic_process_device(self._h, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr()), self._stream())
         else:
@@ -114,8 +140,37 @@ class Plan:
             C.c_void_p(d_out.data_ptr() + 4 * out_offset_px), out_pitch_px, nframes, self._stream()))
         return d_out
 
+    def reconstruct_device(self, d_planar, d_out=None, nframes: int = 1, out_format: int = N.FMT_ARGB8888):
+        """Planar frame buffers of these parameters -> packed pixels (csic_reconstruct_device): ARGB through the inverse
+        transform, or the packed YCbCr stream.  reconstruct(planar(x)) == the packed output of the same parameters."""
+        import torch
+        fb = self.planar_layout.frame_bytes
+        if not d_planar.is_cuda or not d_planar.is_contiguous() or d_planar.numel() * d_planar.element_size() != nframes * fb:
+            raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: d_planar must hold nframes * planar_layout.frame_bytes bytes")
+        shape = (self.out_height, self.out_width) if nframes == 1 else (nframes, self.out_height, self.out_width)
+        if d_out is None:
+            d_out = torch.empty(shape, dtype=torch.int32, device=d_planar.device)
+        elif d_out.numel() != nframes * self.out_width * self.out_height or d_out.element_size() != 4 or not d_out.is_contiguous():
+            raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: d_out has the wrong size/layout")
+        N.check(N.lib().csic_reconstruct_device(self._h, C.c_void_p(d_planar.data_ptr()), C.c_void_p(d_out.data_ptr()), nframes,
+                                                int(out_format), self._stream()))
+        return d_out
+
+    def split_planar(self, buf) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """One planar frame buffer (bytes on the host: numpy uint8, or anything np.frombuffer takes) -> (Y (Ho, Wo), Cb, Cr):
+        the chroma planes as flat arrays of planar_layout.chroma_samples values in sample order."""
+        lay = self.planar_layout
+        b = np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+        n = lay.y_width * lay.y_height
+        return (b[lay.y_offset:lay.y_offset + n].reshape(lay.y_height, lay.y_width),
+                b[lay.cb_offset:lay.cb_offset + lay.chroma_samples], b[lay.cr_offset:lay.cr_offset + lay.chroma_samples])
+
     def process_host(self, argb: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(argb, dtype=np.uint32).reshape(-1)
+        if self.planar:
+            out = np.zeros(self.planar_layout.frame_bytes // 4, dtype=np.uint32)
+            N.check(N.lib().csic_process_host(self._h, a.ctypes.data_as(C.c_void_p), a.size, out.ctypes.data_as(C.c_void_p), out.size))
+            return out.view(np.uint8)
         out = np.empty(self.out_width * self.out_height, dtype=np.uint32)
         N.check(N.lib().csic_process_host(self._h, a.ctypes.data_as(C.c_void_p), a.size,
                                           out.ctypes.data_as(C.c_void_p), out.size))

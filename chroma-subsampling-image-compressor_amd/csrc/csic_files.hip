@@ -26,6 +26,7 @@
 #include <sys/mman.h>
 
 #include "csic_hip_common.h"
+#include "csic_trace.h"
 
 using namespace csic;
 
@@ -132,10 +133,19 @@ void free_slot(Slot &s)                           // the slot is idle: its event
     s = Slot();
 }
 
-void decoder(Shared &sh)
+// A worker must never let an exception leave its thread (std::terminate would take the host process -- a JVM, a Python
+// interpreter -- with it): std::string building, vector growth and deque pushes can all throw std::bad_alloc.  The thread
+// functions below run their loops inside try / catch and turn whatever escapes into the batch's failure.  "out of memory" is
+// short enough for std::string's in-place buffer, so reporting it cannot allocate.
+void fail_nothrow(Shared &sh) noexcept
+{
+    try { fail(sh, CSIC_ENOMEM, "out of memory"); }
+    catch (...) { sh.failed.store(true); sh.cv_free.notify_all(); sh.cv_work.notify_all(); }
+}
+
+void decoder_loop(Shared &sh, double &t_dec, double &t_wait)
 {
     if (hipSetDevice(sh.device) != hipSuccess) { fail(sh, CSIC_EHIP, "decoder thread: cannot make the plan's device current"); }
-    double t_dec = 0, t_wait = 0;
     while (!sh.failed.load()) {
         const int i = sh.next_file.fetch_add(1);
         if (i >= sh.n) break;
@@ -160,11 +170,16 @@ void decoder(Shared &sh)
         }
         Slot &s = sh.slots[slot];
         const auto d0 = Clock::now();
-        int st = csic_png_read_argb(sh.in_paths[i], s.h_in, sh.in_px);             // straight into pinned memory
+        int st;
+        {
+            trace::Range r("csic:decode_png");
+            st = csic_png_read_argb(sh.in_paths[i], s.h_in, sh.in_px);             // straight into pinned memory
+        }
         t_dec += secs(d0, Clock::now());
         if (st != CSIC_OK) { fail(sh, st, std::string("file ") + std::to_string(i) + ": " + csic_last_error()); break; }
         {
             std::lock_guard<std::mutex> lk(sh.launch_mu);
+            trace::Range r("csic:launch_kernel_zero_copy");
             st = launch_on_stream(sh.plan, s.h_in, s.h_out, 1, s.stream);
             if (st == CSIC_OK && hipEventRecord(s.done, s.stream) != hipSuccess) st = set_error(CSIC_EHIP, "hipEventRecord failed");
         }
@@ -176,17 +191,23 @@ void decoder(Shared &sh)
         }
         sh.cv_work.notify_one();
     }
+}
+
+void decoder(Shared &sh) noexcept
+{
+    double t_dec = 0, t_wait = 0;
+    try { decoder_loop(sh, t_dec, t_wait); }
+    catch (...) { fail_nothrow(sh); }
+    // whatever happened above, this decoder is no longer running: the encoders' exit condition depends on the count
     std::lock_guard<std::mutex> lk(sh.mu);
     sh.decode_s += t_dec;
     sh.slot_wait_s += t_wait;
     if (--sh.decoders_running == 0) sh.cv_work.notify_all();
 }
 
-void encoder(Shared &sh)
+void encoder_loop(Shared &sh, double &t_enc, double &t_gpu, int64_t &files)
 {
     if (hipSetDevice(sh.device) != hipSuccess) { fail(sh, CSIC_EHIP, "encoder thread: cannot make the plan's device current"); }
-    double t_enc = 0, t_gpu = 0;
-    int64_t files = 0;
     std::vector<uint32_t> cropped;
     for (;;) {
         int slot = -1, i = -1;
@@ -200,7 +221,11 @@ void encoder(Shared &sh)
         }
         Slot &s = sh.slots[slot];
         const auto g0 = Clock::now();
-        const hipError_t e = hipEventSynchronize(s.done);                          // (also on the failure path: the slot must be idle before it is freed)
+        hipError_t e;
+        {
+            trace::Range r("csic:wait_gpu");
+            e = hipEventSynchronize(s.done);                                       // (also on the failure path: the slot must be idle before it is freed)
+        }
         t_gpu += secs(g0, Clock::now());
         if (e != hipSuccess) fail(sh, CSIC_EHIP, std::string("file ") + std::to_string(i) + ": hipEventSynchronize failed: " + hipGetErrorString(e));
         if (!sh.failed.load()) {
@@ -214,6 +239,7 @@ void encoder(Shared &sh)
                 std::memcpy(cropped.data(), s.h_out, keep * 4);
                 src = cropped.data();
             }
+            trace::Range r("csic:encode_png");
             const int st = png_write_argb_threads(sh.out_paths[i], src, sh.final_w, sh.final_h, sh.level, 1);   // the pool is the parallelism
             t_enc += secs(e0, Clock::now());
             if (st != CSIC_OK) fail(sh, st, std::string("file ") + std::to_string(i) + ": " + csic_last_error());
@@ -229,6 +255,16 @@ void encoder(Shared &sh)
         // 40-odd times in a row after the join (0.1 s of a 0.4 s batch)
         if (retire) free_slot(s); else sh.cv_free.notify_one();
     }
+}
+
+void encoder(Shared &sh) noexcept
+{
+    double t_enc = 0, t_gpu = 0;
+    int64_t files = 0;
+    // An exception that ends the loop early may leave queued frames behind: nobody encodes them (the batch has failed), and the
+    // caller synchronises every slot's stream before freeing it (release()), so no slot is freed under a running kernel.
+    try { encoder_loop(sh, t_enc, t_gpu, files); }
+    catch (...) { fail_nothrow(sh); }
     std::lock_guard<std::mutex> lk(sh.mu);
     sh.encode_s += t_enc;
     sh.gpu_wait_s += t_gpu;
@@ -265,6 +301,8 @@ int csic_process_png_files(csic_plan *plan, const char *const *in_paths, const c
     for (int i = 0; i < nfiles; ++i)
         if (!in_paths[i] || !out_paths[i]) return set_error(CSIC_EINVAL_NULL, "file %d: path is NULL", i);
     if (png_level < 0 || png_level > 9) return set_error(CSIC_EINVAL_SIZE, "png_level must be in 0..9. Got %d", png_level);
+    if (plan_params(plan).out_format == CSIC_FMT_PLANAR)
+        return set_error(CSIC_EINVAL_FORMAT, "the file pools write packed pixels: the plan's out_format must not be CSIC_FMT_PLANAR");
     Shared sh;
     sh.plan = plan;
     sh.device = plan_device(plan);
@@ -273,6 +311,11 @@ int csic_process_png_files(csic_plan *plan, const char *const *in_paths, const c
     sh.final_w = final_width > 0 ? final_width : sh.out_w;
     sh.final_h = final_height > 0 ? final_height : sh.out_h;
     sh.final_px = (size_t)sh.final_w * (size_t)sh.final_h;
+    // the collector's image is never larger than the stream it collects from -- (W / f) x (H / f) against ceil sizes,
+    // ImageCompressorTopApp.scala:44-45 -- so anything far beyond the plan's output is a caller's mistake, refused before a
+    // worker tries to allocate it
+    if (final_width < 0 || final_height < 0 || sh.final_px >= ((size_t)1 << 31) || sh.final_px > 4 * sh.out_px + ((size_t)1 << 20))
+        return set_error(CSIC_EINVAL_SIZE, "final size %dx%d is out of proportion to the plan's %dx%d output", sh.final_w, sh.final_h, sh.out_w, sh.out_h);
     sh.level = png_level;
     sh.in_paths = in_paths; sh.out_paths = out_paths; sh.n = nfiles;
     // the files must be frames of this plan: checked up front so that a wrong batch fails before any thread starts
@@ -286,10 +329,21 @@ int csic_process_png_files(csic_plan *plan, const char *const *in_paths, const c
             return set_error(CSIC_EINVAL_SIZE, "%s is %dx%d, the plan processes %dx%zu frames", in_paths[i], w, h, plan_width(plan),
                              sh.in_px / (size_t)plan_width(plan));
     }
-    unsigned hw = std::thread::hardware_concurrency();
-    if (hw == 0) hw = 4;
-    int D = decode_threads > 0 ? decode_threads : (int)(hw < 32 ? hw : 32);
-    int E = encode_threads > 0 ? encode_threads : (int)(hw < 16 ? hw : 16);
+    // Defaults from the CPU time the process may really use (affinity mask and cgroup quota, host_cpu_budget) -- not from the
+    // CPUs the machine shows: a GPU box shows 256 and grants 16.  Twice the budget, because a worker also waits (file reads,
+    // slot hand-offs, the GPU): measured on that box, 24 + 8 and 32 + 16 threads finish cfg 5 in 0.29-0.30 s, 16 + 8 in 0.33 s
+    // and 12 + 4 in 0.40 s (profiles/r03_probe_files_wall.log).  Two thirds decode, one third encode -- a 4K frame costs 45-49 ms
+    // to decode and 23 ms to encode.  At most 32 + 16 as before; the numbers chosen are reported in csic_files_stats.
+    const int budget = host_cpu_budget();
+    int total = 2 * budget;
+    if (total > 48) total = 48;
+    if (total < 2) total = 2;
+    int defD = (2 * total + 2) / 3, defE = total - defD;
+    if (defD > 32) defD = 32;
+    if (defE > 16) defE = 16;
+    if (defE < 1) defE = 1;
+    int D = decode_threads > 0 ? decode_threads : defD;
+    int E = encode_threads > 0 ? encode_threads : defE;
     if (D > nfiles) D = nfiles;
     if (E > nfiles) E = nfiles;
     if (D > 256) D = 256;

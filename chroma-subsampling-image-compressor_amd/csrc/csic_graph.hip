@@ -163,10 +163,30 @@ static int engine_grow(DirectEngine *e, int nq)
     return CSIC_OK;
 }
 
+// every packet the engine ever published has been taken off its ring
+static bool engine_drained(const DirectEngine *e)
+{
+    for (int i = 0; i < e->nq; ++i)
+        if (hsa_queue_load_read_index_scacquire(e->q[i]) != hsa_queue_load_write_index_relaxed(e->q[i])) return false;
+    return true;
+}
+
+
 static int engine_acquire(int device, int nq, DirectEngine **out)
 {
     std::lock_guard<std::mutex> lk(g_engines_mu);
     auto it = g_engines.find(device);
+    if (it != g_engines.end() && it->second->failed) {
+        // A failed engine stays in the table as the device's tombstone (engine_release never erases it): no second set of
+        // queues is built beside queues that may still hold a hole.  It is only replaced once nothing uses it any more AND
+        // every packet it published has been consumed -- then the hole has drained and a fresh engine cannot queue behind it.
+        DirectEngine *dead = it->second;
+        if (dead->refs > 0 || !engine_drained(dead))
+            return set_error(CSIC_EHIP, "the direct-dispatch engine of device %d failed earlier: %s", device, dead->failure.c_str());
+        g_engines.erase(it);
+        engine_free(dead);
+        it = g_engines.end();
+    }
     if (it != g_engines.end()) {
         DirectEngine *e = it->second;
         {
@@ -195,8 +215,9 @@ static void engine_release(DirectEngine *e)
 {
     std::lock_guard<std::mutex> lk(g_engines_mu);
     if (--e->refs > 0) return;
+    if (e->failed) return;                      // stays in g_engines as the device's tombstone: its queues may still hold packets
+                                                // (see DirectEngine::failed; engine_acquire replaces it once they have drained)
     g_engines.erase(e->device);
-    if (e->failed) return;                      // leaked on purpose: its queues may still hold packets (see DirectEngine::failed)
     engine_free(e);
 }
 
@@ -657,18 +678,26 @@ static int wait_slot(csic_frame_graph *g, int64_t ticket)
                 if ((spins & 63) == 0) {
                     clock_gettime(CLOCK_MONOTONIC, &now);
                     const double el = (double)(now.tv_sec - t0.tv_sec) + 1e-9 * (double)(now.tv_nsec - t0.tv_nsec);
-                    if (el > 2.0e-8 * (double)g->timeout_ticks + 5.0)          // both device spins have timed out by then
+                    if (el > 2.0e-8 * (double)g->timeout_ticks + 5.0) {        // both device spins have timed out by then
+                        g->poisoned = true;                                     // nothing of this graph may be re-armed or freed any more
                         return set_error(CSIC_EHIP, "direct dispatch: launch %lld did not pass its hand-off in time", (long long)g->slot_ticket[slot]);
+                    }
                     if (el > 2.0e-4) { const timespec nap{0, 20000}; nanosleep(&nap, nullptr); }
                 }
             }
         } else {
             HIP_TRY(hipEventSynchronize(g->consumed[slot]));
         }
-        g->slot_on_stream[slot] = false;
-        if (g->err_word && *g->err_word)
+        if (g->err_word && *g->err_word) {
+            // A gate or a hand-off gave up: the slot's queues may still be running (a kernel-gated submission's queue 0 does not
+            // wait for the others), so the slot is neither marked idle nor ever waited for through the host-ordered path -- the
+            // graph is poisoned: every later wait / launch / submit reports it, and destroy leaks its device words instead of
+            // freeing them under packets that may still run.
+            g->poisoned = true;
             return set_error(CSIC_EHIP, "direct dispatch: a stream-ordered launch timed out waiting for %s (flags %u)",
                              (*g->err_word & 1u) ? "its gate" : "its queues", *g->err_word);
+        }
+        g->slot_on_stream[slot] = false;
         return CSIC_OK;
     }
     // done[slot][0] is completed by queue 0's closing packet, which depends on every other queue's closing signal

@@ -71,6 +71,14 @@ int prepare_launch_table(const csic_plan *pl, const void *const *d_in_tab, void 
 int enqueue(const LaunchDesc &d, hipStream_t stream);
 int launch_on_stream(csic_plan *pl, const void *d_in, void *d_out, int nframes, hipStream_t stream);
 int plan_device(const csic_plan *pl);
+const csic_params &plan_params(const csic_plan *pl);
+const Geometry &plan_geometry(const csic_plan *pl);
+int plan_variant(const csic_plan *pl);                       // CSIC_TUNE_VARIANT
+bool plan_nontemporal(const csic_plan *pl);                  // CSIC_TUNE_NONTEMPORAL
+void fill_base_args(const Geometry &g, int32_t ip, int32_t op, KArgs *a);
+// csic_planar.hip: out_format = CSIC_FMT_PLANAR (forward: packed input -> planar frame buffers; name of the kernel a plan takes)
+int planar_forward(const csic_plan *pl, const void *d_in, void *d_planar, int nframes, hipStream_t stream);
+void planar_kernel_name(const csic_plan *pl, char *buf, size_t len);
 void plan_sizes(const csic_plan *pl, size_t *in_px, size_t *out_px);
 int32_t plan_width(const csic_plan *pl);
 void plan_out_dims(const csic_plan *pl, int32_t *wo, int32_t *ho);

@@ -4,11 +4,79 @@
 //
 // Citations are relative to /root/reference/.
 #include "csic_internal.h"
+#include "csic_trace.h"
 
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+
+#include <dlfcn.h>
+#include <sched.h>
 
 namespace csic {
+
+// ---- optional roctx markers (csic_trace.h) ------------------------------------------------------------------------------
+namespace trace {
+namespace {
+using push_fn = int (*)(const char *);
+using pop_fn = int (*)();
+std::atomic<int> g_state{0};                  // 0 = not looked yet, 1 = on, 2 = off
+push_fn g_push = nullptr;
+pop_fn g_pop = nullptr;
+std::once_flag g_once;
+
+void look()
+{
+    const char *env = std::getenv("CSIC_ROCTX");
+    if (env && *env && std::strcmp(env, "0") != 0) {
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            g_push = reinterpret_cast<push_fn>(dlsym(h, "roctxRangePushA"));
+            g_pop = reinterpret_cast<pop_fn>(dlsym(h, "roctxRangePop"));
+            if (g_push && g_pop) break;
+            g_push = nullptr; g_pop = nullptr;
+        }
+    }
+    g_state.store(g_push && g_pop ? 1 : 2, std::memory_order_release);
+}
+} // namespace
+
+bool enabled()
+{
+    int s = g_state.load(std::memory_order_acquire);
+    if (s == 0) { std::call_once(g_once, look); s = g_state.load(std::memory_order_acquire); }
+    return s == 1;
+}
+void push(const char *name) { if (g_push) (void)g_push(name); }
+void pop() { if (g_pop) (void)g_pop(); }
+} // namespace trace
+
+int host_cpu_budget()
+{
+    int n = 0;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = 4;
+    // cgroup v2 cpu.max ("<quota> <period>" or "max ..."), then v1 cfs quota
+    long long q = -1, per = -1;
+    if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[32] = "", b[32] = "";
+        if (std::fscanf(fp, "%31s %31s", a, b) == 2 && std::strcmp(a, "max") != 0) { q = std::atoll(a); per = std::atoll(b); }
+        std::fclose(fp);
+    } else {
+        if (FILE *fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(fq, "%lld", &q) != 1) q = -1; std::fclose(fq); }
+        if (FILE *fr = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(fr, "%lld", &per) != 1) per = -1; std::fclose(fr); }
+    }
+    if (q > 0 && per > 0) {
+        const int quota = (int)((q + per - 1) / per);
+        if (quota >= 1 && quota < n) n = quota;
+    }
+    return n < 1 ? 1 : n;
+}
 
 static thread_local char g_last_error[512] = "";
 
@@ -68,8 +136,8 @@ static int validate_impl(const csic_params *p)
         return set_error(CSIC_EINVAL_SAMPLING, "the AVG extension is defined for the order chroma -> spatial -> quant only");
     if (p->in_format != CSIC_FMT_ARGB8888 && p->in_format != CSIC_FMT_YCBCR888X)
         return set_error(CSIC_EINVAL_FORMAT, "in_format must be ARGB8888(0) or YCBCR888X(1). Got %d", p->in_format);
-    if (p->out_format != CSIC_FMT_ARGB8888 && p->out_format != CSIC_FMT_YCBCR888X)
-        return set_error(CSIC_EINVAL_FORMAT, "out_format must be ARGB8888(0) or YCBCR888X(1). Got %d", p->out_format);
+    if (p->out_format != CSIC_FMT_ARGB8888 && p->out_format != CSIC_FMT_YCBCR888X && p->out_format != CSIC_FMT_PLANAR)
+        return set_error(CSIC_EINVAL_FORMAT, "out_format must be ARGB8888(0), YCBCR888X(1) or PLANAR(2). Got %d", p->out_format);
     // ImageProcessor.scala:25 -- a rule of ImageProcessorParams only; the raw RTL accepts any size
     if (p->strict_divisible && (p->width % p->factor != 0 || p->height % p->factor != 0))
         return set_error(CSIC_EINVAL_NOT_DIVISIBLE,
@@ -99,6 +167,34 @@ int derive_geometry(const csic_params *p, Geometry *g)
     g->mask_cb = (0xFFu << (8 - p->cb_bits)) & 0xFFu;
     g->mask_cr = (0xFFu << (8 - p->cr_bits)) & 0xFFu;
     return CSIC_OK;
+}
+
+// The planar layout of csic.h (see the definition there): where the chroma stage sits decides which counters the output sees.
+void planar_layout(const Geometry &g, const csic_params *p, csic_planar_layout *L)
+{
+    const int64_t n = (int64_t)g.Wo * g.Ho;
+    L->y_width = g.Wo; L->y_height = g.Ho;
+    if (p->sampling == CSIC_SAMPLING_AVG) {
+        L->module_width = g.Wo; L->hold_h = g.h > g.f ? g.h / g.f : 1; L->hold_v = g.v > g.f ? g.v / g.f : 1; L->replay_last = 0;
+    } else if (g.s_first || g.f == 1) {                       // the chroma counters run over the (decimated) stream, full width
+        L->module_width = g.W; L->hold_h = g.h; L->hold_v = g.v; L->replay_last = 1;
+    } else {                                                  // chroma before the decimator: image coordinates, every f-th kept
+        L->module_width = g.Wo; L->hold_h = g.h > g.f ? g.h / g.f : 1; L->hold_v = 1; L->replay_last = 1;
+    }
+    const int64_t Wm = L->module_width, rows = (n + Wm - 1) / Wm;           // chroma rows, the last one possibly partial
+    L->chroma_width = (int32_t)((Wm + L->hold_h - 1) / L->hold_h);
+    L->chroma_height = (int32_t)((rows + L->hold_v - 1) / L->hold_v);
+    // samples that exist: full sample rows, and what the last chroma row holds if it is a sample row
+    const int64_t last_len = n - (rows - 1) * Wm, last_is_sample_row = ((rows - 1) % L->hold_v) == 0;
+    L->chroma_samples = (int64_t)(L->chroma_height - (last_is_sample_row ? 1 : 0)) * L->chroma_width +
+                        (last_is_sample_row ? (last_len + L->hold_h - 1) / L->hold_h : 0);
+    auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
+    const int64_t plane = (int64_t)L->chroma_width * L->chroma_height;
+    L->y_offset = 0;
+    L->cb_offset = up(n);
+    L->cr_offset = L->cb_offset + up(plane);
+    L->frame_bytes = L->cr_offset + up(plane);
+    L->payload_bytes = n + 2 * L->chroma_samples;
 }
 
 void magic_div(uint32_t d, uint32_t *m, uint32_t *k)
@@ -160,8 +256,27 @@ int csic_algorithmic_bytes(const csic_params *p, int64_t *bytes)
     if (st != CSIC_OK) return st;
     // every byte of each input row that holds a surviving pixel + the output;
     // with AVG sampling every input row is live: A_avg = 4*W*H + 4*Wo*Ho
-    if (p->sampling == CSIC_SAMPLING_AVG) *bytes = 4ll * g.W * g.H + 4ll * g.Wo * g.Ho;
-    else                                  *bytes = 4ll * g.W * g.Ho + 4ll * g.Wo * g.Ho;
+    // planar output: the same input bytes, and the payload the format stores instead of 4 bytes per output pixel
+    int64_t out_bytes = 4ll * g.Wo * g.Ho;
+    if (p->out_format == CSIC_FMT_PLANAR) {
+        csic_planar_layout L;
+        planar_layout(g, p, &L);
+        out_bytes = L.payload_bytes;
+    }
+    if (p->sampling == CSIC_SAMPLING_AVG) *bytes = 4ll * g.W * g.H + out_bytes;
+    else                                  *bytes = 4ll * g.W * g.Ho + out_bytes;
+    clear_error();
+    return CSIC_OK;
+}
+
+int csic_planar_layout_of(const csic_params *p, csic_planar_layout *layout)
+{
+    if (!layout) return set_error(CSIC_EINVAL_NULL, "layout is NULL");
+    Geometry g;
+    int st = derive_geometry(p, &g);
+    if (st != CSIC_OK) return st;
+    std::memset(layout, 0, sizeof *layout);
+    planar_layout(g, p, layout);
     clear_error();
     return CSIC_OK;
 }

@@ -22,6 +22,7 @@ struct Geometry {
 int  set_error(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void clear_error();
 int  derive_geometry(const csic_params *p, Geometry *g);   // validates first
+void planar_layout(const Geometry &g, const csic_params *p, csic_planar_layout *layout);   // csic.h: CSIC_FMT_PLANAR
 
 // Exact unsigned division by a run-time constant without a divide (k_generic's stream-index arithmetic): for
 // 1 <= d < 2^31 and every n < 2^31,  n / d == (uint64(n) * m) >> k  with  k = 31 + ceil(log2 d),  m = ceil(2^k / d) < 2^32.

@@ -37,176 +37,9 @@
 #include <tuple>
 #include <utility>
 
-#include "csic_hip_common.h"
+#include "csic_kernel_ops.h"
 
 namespace csic {
-
-// Wave prologue.  hipcc sinks every kernel-argument s_load to its first use, and blockDim/gridDim come
-// from the hidden-argument area, so a kernel with early exits pays 3-4 DEPENDENT scalar-load round
-// trips (~0.4 us) before its first global load -- 5 % of the f=1 kernel, whose waves hold a single
-// 16-byte load in flight.  Pinning the arguments in SGPRs at entry turns that into one batch and one
-// s_waitcnt; the launch geometry travels in KArgs for the same reason.
-__device__ __forceinline__ void pin_args(const KArgs &a)
-{
-    asm volatile("" ::"s"(a.in), "s"(a.out), "s"(a.W), "s"(a.H), "s"(a.Wo), "s"(a.Ho), "s"(a.last_sample_col));
-    asm volatile("" ::"s"(a.my), "s"(a.mcb), "s"(a.mcr), "s"(a.in_frame_px), "s"(a.out_frame_px), "s"(a.bdx),
-                 "s"(a.bdy), "s"(a.row_step), "s"(a.ip), "s"(a.op), "s"(a.in_tab), "s"(a.out_tab));
-}
-
-// Pixel pointers carry their address space.  A pointer that was itself loaded from memory (frame-table mode) is
-// a generic pointer to the compiler, and every access through it becomes a flat_load / flat_store with a 64-bit
-// per-lane address and an lgkmcnt dependency; the frames are always global memory, so say so.
-#define CSIC_GLOBAL __attribute__((address_space(1)))
-#define CSIC_CONSTANT __attribute__((address_space(4)))
-typedef const uint32_t CSIC_GLOBAL *gin_t;
-typedef uint32_t CSIC_GLOBAL *gout_t;
-
-// Base of the frame this block works on (grid z = frame): consecutive frames behind a.in / a.out, or -- frame-table mode --
-// whatever the device-resident tables name.  The tables are read through the constant address space (they are never
-// written while a kernel runs): one wave-uniform s_load, the frame base stays in SGPRs.
-__device__ __forceinline__ gin_t frame_in(const KArgs &a)
-{
-    if (a.in_tab) return (gin_t)((const uint64_t CSIC_CONSTANT *)(uintptr_t)a.in_tab)[blockIdx.z];
-    return (gin_t)(uintptr_t)a.in + (int64_t)blockIdx.z * a.in_frame_px;
-}
-__device__ __forceinline__ gout_t frame_out(const KArgs &a)
-{
-    if (a.out_tab) return (gout_t)((const uint64_t CSIC_CONSTANT *)(uintptr_t)a.out_tab)[blockIdx.z];
-    return (gout_t)(uintptr_t)a.out + (int64_t)blockIdx.z * a.out_frame_px;
-}
-
-enum { R_FLOOR = CSIC_ROUND_FLOOR_HW, R_TRUNC = CSIC_ROUND_TRUNC_SW };
-enum { F_ARGB = CSIC_FMT_ARGB8888, F_YCC = CSIC_FMT_YCBCR888X };
-
-// ------------------------------------------------------------------------------------------------
-// streaming memory access
-// ------------------------------------------------------------------------------------------------
-// Frames are read once and written once and are far larger than L2 (4 MiB/XCD): non-temporal
-// ("nt") loads and stores keep the stream from displacing itself in the cache hierarchy.  Measured on
-// MI355X at 8192x8192, f=2 (tools/ubench.hip): 35.9 -> 33.5 us per frame, the same gain a plain
-// 16 B/lane copy kernel sees (6.03 -> 6.41 TB/s).
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-template <bool NT> __device__ __forceinline__ uint32_t ld1(gin_t p)
-{ return NT ? __builtin_nontemporal_load(p) : *p; }
-template <bool NT> __device__ __forceinline__ u32x4 ld4(gin_t p)
-{ typedef const u32x4 CSIC_GLOBAL *vp; return NT ? __builtin_nontemporal_load((vp)p) : *(vp)p; }
-template <bool NT> __device__ __forceinline__ void st1(gout_t p, uint32_t v)
-{ if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
-template <bool NT> __device__ __forceinline__ void st2(gout_t p, u32x2 v)
-{ typedef u32x2 CSIC_GLOBAL *vp; if (NT) __builtin_nontemporal_store(v, (vp)p); else *(vp)p = v; }
-template <bool NT> __device__ __forceinline__ void st4(gout_t p, u32x4 v)
-{ typedef u32x4 CSIC_GLOBAL *vp; if (NT) __builtin_nontemporal_store(v, (vp)p); else *(vp)p = v; }
-// the same through plain pointers (kernel arguments: the compiler infers global itself; tools/ubench*.hip)
-template <bool NT> __device__ __forceinline__ uint32_t ld1(const uint32_t *p) { return ld1<NT>((gin_t)(uintptr_t)p); }
-template <bool NT> __device__ __forceinline__ u32x4 ld4(const uint32_t *p) { return ld4<NT>((gin_t)(uintptr_t)p); }
-template <bool NT> __device__ __forceinline__ void st1(uint32_t *p, uint32_t v) { st1<NT>((gout_t)(uintptr_t)p, v); }
-template <bool NT> __device__ __forceinline__ void st2(uint32_t *p, u32x2 v) { st2<NT>((gout_t)(uintptr_t)p, v); }
-template <bool NT> __device__ __forceinline__ void st4(uint32_t *p, u32x4 v) { st4<NT>((gout_t)(uintptr_t)p, v); }
-
-// ------------------------------------------------------------------------------------------------
-// per-pixel arithmetic
-// ------------------------------------------------------------------------------------------------
-// Pixel bytes (little endian uint32): b0 = B, b1 = G, b2 = R, b3 = A.
-
-// Y = (77R + 150G + 29B + 128) >> 8.  The sum is non-negative, so floor == trunc, and
-// 77 + 150 + 29 = 256 bounds it by 255: no clamp can fire.  One v_dot4_u32_u8 + one shift.
-__device__ __forceinline__ uint32_t fwd_y(uint32_t px)
-{
-    return __builtin_amdgcn_udot4(px, 0x004D961Du /* A:0 R:77 G:150 B:29 */, 128u, false) >> 8;
-}
-
-// Cb/Cr with the UNSIGNED dot product.  The negatively weighted bytes are complemented first
-// (-43 R = 43 (255 - R) - 43*255), which turns every coefficient into a u8 and moves the sign into a constant:
-//   cbI = -43R - 85G + 128B = udot4(px ^ 0x00FFFF00, {R:43, G:85, B:128}) - 32640
-//   crI = 128R - 107G - 21B = udot4(px ^ 0x0000FFFF, {R:128, G:107, B:21}) - 32640
-// FLOOR: ((cbI + 128) >> 8) + 128 == (cbI + 32896) >> 8 == (udot + 256) >> 8, with the +256 riding in the
-// dot's accumulator: xor, v_dot4_u32_u8, shift, min -- 4 VALU ops per channel (the signed v_dot4c_i32_i8
-// form needs an accumulator-init move and a subtract on top).  The only clamp that can fire is 256 -> 255
-// (SURVEY.md App. A.1).  TRUNC (Scala's '/' rounds toward zero): negative numerators cbI + 128 < 0, i.e.
-// udot < 32512, round up instead: (udot + 511) >> 8.
-template <int ROUND>
-__device__ __forceinline__ void fwd_c(uint32_t px, uint32_t &cb, uint32_t &cr)
-{
-    const uint32_t ub = __builtin_amdgcn_udot4(px ^ 0x00FFFF00u, 0x002B5580u /* A:0 R:43  G:85  B:128 */, 256u, false);
-    const uint32_t ur = __builtin_amdgcn_udot4(px ^ 0x0000FFFFu, 0x00806B15u /* A:0 R:128 G:107 B:21  */, 256u, false);
-    if (ROUND == R_FLOOR) {
-        cb = min(ub >> 8, 255u);
-        cr = min(ur >> 8, 255u);
-    } else {
-        // ub, ur carry the +256 already: the "negative numerator" test is udot + 256 < 32768
-        cb = min((ub + (ub < 32768u ? 255u : 0u)) >> 8, 255u);
-        cr = min((ur + (ur < 32768u ? 255u : 0u)) >> 8, 255u);
-    }
-}
-
-// (Y, Cb, Cr) of an input pixel: the forward transform, or plain unpacking for a YCbCr input stream
-template <int ROUND, int INFMT>
-__device__ __forceinline__ uint32_t in_y(uint32_t px) { return INFMT == F_YCC ? (px & 0xFFu) : fwd_y(px); }
-template <int ROUND, int INFMT>
-__device__ __forceinline__ void in_c(uint32_t px, uint32_t &cb, uint32_t &cr)
-{
-    if (INFMT == F_YCC) { cb = (px >> 8) & 0xFFu; cr = (px >> 16) & 0xFFu; }
-    else fwd_c<ROUND>(px, cb, cr);
-}
-
-// Chroma-dependent part of the inverse transform, shared by all pixels that hold the same chroma.
-//   R = clamp((298Y + 409(Cr-128) + 128) >> 8)                 = clamp((298Y + KR) >> 8)
-//   G = clamp((298Y - 100(Cb-128) - 208(Cr-128) + 128) >> 8)   = clamp((298Y + KG) >> 8)
-//   B = clamp((298Y + 516(Cb-128) + 128) >> 8)                 = clamp((298Y + KB) >> 8)
-struct ChromaTerm {
-    int kr, kg, kb;      // ARGB output
-    uint32_t ycc_hi;     // YCC output: Cb << 8 | Cr << 16
-};
-
-// from already quantised Cb, Cr
-template <int FMT>
-__device__ __forceinline__ ChromaTerm chroma_term_q(uint32_t cb, uint32_t cr)
-{
-    ChromaTerm t;
-    if (FMT == F_ARGB) {
-        t.kr = __mul24((int)cr, 409) - 52224;
-        t.kb = __mul24((int)cb, 516) - 65920;
-        t.kg = 39552 - __mul24((int)cb, 100) - __mul24((int)cr, 208);
-        t.ycc_hi = 0;
-    } else {
-        t.kr = t.kg = t.kb = 0;
-        t.ycc_hi = (cb << 8) | (cr << 16);
-    }
-    return t;
-}
-
-template <int ROUND, int FMT>
-__device__ __forceinline__ ChromaTerm chroma_term(uint32_t cpx, uint32_t mcb, uint32_t mcr)
-{
-    uint32_t cb, cr;
-    fwd_c<ROUND>(cpx, cb, cr);
-    return chroma_term_q<FMT>(cb & mcb, cr & mcr);      // quantiser, ColorQuantizer.scala:43-44
-}
-
-__device__ __forceinline__ int clamp_u8(int v) { return min(max(v, 0), 255); }   // -> v_med3_i32
-
-// from an already quantised Y
-template <int FMT>
-__device__ __forceinline__ uint32_t finish_y(uint32_t y, const ChromaTerm &t)
-{
-    if (FMT == F_ARGB) {
-        const int yy = __mul24((int)y, 298);
-        const int r = clamp_u8((yy + t.kr) >> 8);
-        const int g = clamp_u8((yy + t.kg) >> 8);
-        const int b = clamp_u8((yy + t.kb) >> 8);
-        return 0xFF000000u | ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;
-    } else {
-        return y | t.ycc_hi;
-    }
-}
-
-template <int FMT>
-__device__ __forceinline__ uint32_t finish(uint32_t ypx, uint32_t my, const ChromaTerm &t)
-{
-    return finish_y<FMT>(fwd_y(ypx) & my, t);           // quantiser, ColorQuantizer.scala:42
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_f1x4: factor 1, W % 4 == 0, 4 pixels per lane
@@ -229,8 +62,8 @@ __global__ void __launch_bounds__(256) k_f1x4(KArgs a)
         // issued ahead of the 16-byte stream load so that the two latencies overlap.
         const bool odd = (VV == 2) && (row & 1);
         uint32_t cpx = 0;
-        if (odd) cpx = in[(int64_t)(row - 1) * a.ip + a.last_sample_col];
-        const u32x4 p = ld4<NT>(in + base);
+        if (odd) cpx = in1<false>(a, in, (int64_t)(row - 1) * a.ip + a.last_sample_col);
+        const u32x4 p = in4<NT>(a, in, base);
         const uint32_t px[4] = {p.x, p.y, p.z, p.w};
         uint32_t o[4];
         if (odd) {
@@ -246,7 +79,7 @@ __global__ void __launch_bounds__(256) k_f1x4(KArgs a)
             }
         }
         const u32x4 ov = {o[0], o[1], o[2], o[3]};
-        st4<NT>(out + obase, ov);
+        out4<NT>(a, out, obase, ov);
     }
 }
 
@@ -278,7 +111,7 @@ __device__ __forceinline__ uint32_t hold_in_quad(uint32_t v)
 // s_waitcnt vmcnt(0) in front of every store, which serialises the stores (38.0 vs 32.7 us per frame).
 // BCAST: the whole row replays one chroma pixel (`bpx`).
 template <int ROUND, int FMT, int F, int HOLD, bool BCAST, int K, bool NT, bool CHECK>
-__device__ __forceinline__ void dec_chunk(const KArgs &a, gin_t rowp, gout_t orow, int co0, int bx,
+__device__ __forceinline__ void dec_chunk(const KArgs &a, gin_t in, int64_t rowoff, gout_t out, int64_t orowoff, int co0, int bx,
                                           uint32_t bpx)
 {
     uint32_t px[K];
@@ -287,14 +120,14 @@ __device__ __forceinline__ void dec_chunk(const KArgs &a, gin_t rowp, gout_t oro
         // partial chunk: clamp the column instead of branching, so the K loads still issue back to back
         // (out-of-row lanes re-read the last pixel of the row and simply do not store)
         const int co = CHECK ? min(co0 + k * bx, a.Wo - 1) : co0 + k * bx;
-        px[k] = ld1<NT>(rowp + co * F);
+        px[k] = in1<NT>(a, in, rowoff + co * F);
     }
     if (BCAST) {
         const ChromaTerm t = chroma_term<ROUND, FMT>(bpx, a.mcb, a.mcr);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int co = co0 + k * bx;
-            if (!CHECK || co < a.Wo) st1<NT>(orow + co, finish<FMT>(px[k], a.my, t));
+            if (!CHECK || co < a.Wo) out1<NT>(a, out, orowoff + co, finish<FMT>(px[k], a.my, t));
         }
     } else {
         uint32_t cpx[K];
@@ -305,7 +138,7 @@ __device__ __forceinline__ void dec_chunk(const KArgs &a, gin_t rowp, gout_t oro
             const int co = co0 + k * bx;
             if (!CHECK || co < a.Wo) {
                 const ChromaTerm t = chroma_term<ROUND, FMT>(cpx[k], a.mcb, a.mcr);
-                st1<NT>(orow + co, finish<FMT>(px[k], a.my, t));
+                out1<NT>(a, out, orowoff + co, finish<FMT>(px[k], a.my, t));
             }
         }
     }
@@ -316,18 +149,18 @@ __device__ __forceinline__ void dec_rows(const KArgs &a, gin_t in, gout_t out, i
                                          int ro0, int row_step)
 {
     for (int ro = ro0; ro < a.Ho; ro += row_step) {
-        const gin_t rowp = in + (int64_t)(ro * F) * a.ip;
-        const gout_t orow = out + (int64_t)ro * a.op;
+        const int64_t rowoff = (int64_t)(ro * F) * a.ip;
+        const int64_t orowoff = (int64_t)ro * a.op;
         if (SROWS) {
             const int r = ro >> a.sc_shift;                               // chroma row = ro / F
             if (r & a.vmask) {                                            // odd chroma row of 4:x:0
                 const int srow = ((r - 1) << a.sc_shift) + a.bc_row_off; // decimated row of the held sample
-                const uint32_t bpx = in[(int64_t)(srow * F) * a.ip + a.bc_col_in];
-                dec_chunk<ROUND, FMT, F, HOLD, true, K, NT, CHECK>(a, rowp, orow, co0, bx, bpx);
+                const uint32_t bpx = in1<false>(a, in, (int64_t)(srow * F) * a.ip + a.bc_col_in);
+                dec_chunk<ROUND, FMT, F, HOLD, true, K, NT, CHECK>(a, in, rowoff, out, orowoff, co0, bx, bpx);
                 continue;
             }
         }
-        dec_chunk<ROUND, FMT, F, HOLD, false, K, NT, CHECK>(a, rowp, orow, co0, bx, 0u);
+        dec_chunk<ROUND, FMT, F, HOLD, false, K, NT, CHECK>(a, in, rowoff, out, orowoff, co0, bx, 0u);
     }
 }
 
@@ -379,7 +212,7 @@ __device__ __forceinline__ void decflat_body(const KArgs &a, gin_t in, gout_t ou
         const uint32_t ro = (uint32_t)(((uint64_t)i * a.mWo) >> a.kWo);          // i / Wo, exact for i < 2^31
         const uint32_t co = i - ro * (uint32_t)a.Wo;
         const int64_t yoff = (int64_t)(ro * F) * a.ip + co * F;
-        px[k] = ld1<NT>(in + yoff);
+        px[k] = in1<NT>(a, in, yoff);
         oo[k] = (int64_t)ro * a.op + co;
         if (SROWS) {
             const int r = (int)(ro >> a.sc_shift);                                // chroma row = ro / F
@@ -394,7 +227,7 @@ __device__ __forceinline__ void decflat_body(const KArgs &a, gin_t in, gout_t ou
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             hp[k] = 0;
-            if (__builtin_amdgcn_ballot_w64(odd[k]) != 0) hp[k] = ld1<false>(in + ho[k]);
+            if (__builtin_amdgcn_ballot_w64(odd[k]) != 0) hp[k] = in1<false>(a, in, ho[k]);
         }
     }
     uint32_t cpx[K];
@@ -405,7 +238,7 @@ __device__ __forceinline__ void decflat_body(const KArgs &a, gin_t in, gout_t ou
         if (!CHECK || i0 + (uint32_t)k * T < n) {
             const uint32_t c = (SROWS && odd[k]) ? hp[k] : cpx[k];
             const ChromaTerm t = chroma_term<ROUND, FMT>(c, a.mcb, a.mcr);
-            st1<NT>(out + oo[k], finish<FMT>(px[k], a.my, t));
+            out1<NT>(a, out, oo[k], finish<FMT>(px[k], a.my, t));
         }
     }
 }
@@ -442,24 +275,24 @@ __global__ void __launch_bounds__(256) k_dec2v(KArgs a)
     const gout_t out = frame_out(a);
     const int row_step = a.row_step;
     for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += row_step) {
-        const gin_t rowp = in + (int64_t)(ro * 2) * a.ip + (int64_t)x * (OPL * 2);
-        const gout_t op = out + (int64_t)ro * a.op + (int64_t)x * OPL;
+        const int64_t ioff = (int64_t)(ro * 2) * a.ip + (int64_t)x * (OPL * 2);
+        const int64_t ooff = (int64_t)ro * a.op + (int64_t)x * OPL;
         if (VAR == 1) {
-            const u32x4 p = ld4<NT>(rowp);
+            const u32x4 p = in4<NT>(a, in, ioff);
             const ChromaTerm t0 = chroma_term<ROUND, FMT>(p.x, a.mcb, a.mcr);
             const ChromaTerm t1 = chroma_term<ROUND, FMT>(p.z, a.mcb, a.mcr);
             const u32x2 ov = {finish<FMT>(p.x, a.my, t0), finish<FMT>(p.z, a.my, t1)};
-            st2<NT>(op, ov);
+            out2<NT>(a, out, ooff, ov);
         } else {
-            const u32x4 p = ld4<NT>(rowp);
-            const u32x4 q = ld4<NT>(rowp + 4);
+            const u32x4 p = in4<NT>(a, in, ioff);
+            const u32x4 q = in4<NT>(a, in, ioff + 4);
             const ChromaTerm t0 = chroma_term<ROUND, FMT>(p.x, a.mcb, a.mcr);
             const ChromaTerm t1 = chroma_term<ROUND, FMT>(p.z, a.mcb, a.mcr);
             const ChromaTerm t2 = chroma_term<ROUND, FMT>(q.x, a.mcb, a.mcr);
             const ChromaTerm t3 = chroma_term<ROUND, FMT>(q.z, a.mcb, a.mcr);
             const u32x4 ov = {finish<FMT>(p.x, a.my, t0), finish<FMT>(p.z, a.my, t1),
                               finish<FMT>(q.x, a.my, t2), finish<FMT>(q.z, a.my, t3)};
-            st4<NT>(op, ov);
+            out4<NT>(a, out, ooff, ov);
         }
     }
 }
@@ -472,121 +305,157 @@ __global__ void __launch_bounds__(256) k_dec2v(KArgs a)
 // does sample-and-hold + decimation (k_dec / k_f1x4 above).  Normative statement: oracle/csic_oracle.c
 // orc_process_avg.  All input rows are live here: algorithmic bytes = 4*W*H + 4*Wo*Ho.
 //
-// k_avg (fast path, W % TW == 0, H % TH == 0, 16-byte aligned): one lane owns a 4-pixel-wide, TH-row
-// tile (TH = max(v, f)) = TH dense 16-byte loads, so every chroma block and every pooling block with
-// f <= 4 lies inside one lane's registers -- no LDS line buffer and no cross-lane traffic is needed.
+// k_avg: one lane owns a 4-pixel-wide, TH-row tile (TH = max(v, f)) = TH 16-byte loads, so every chroma block and every
+// pooling block with f <= 4 lies inside one lane's registers -- no LDS line buffer and no cross-lane traffic is needed.
 // f = 8 spans two lanes: each sums its 4 x 8 half and the halves meet through one DPP quad_perm swap.
+//
+// Any frame shape (round 4; rounds 1-3 needed W % 4 == 0, H % TH == 0, Wo % 4 == 0 and 16-byte aligned rows, and everything
+// else -- 1366x768, 1001x1001, but also 1368x768 at f = 4, whose OUTPUT rows are 342 pixels -- fell to the one-pixel-per-lane
+// kernel at a tenth of the speed).  Tiles that lie inside the frame take the register path; the tiles of the last column /
+// last tile row that the frame cuts take orc_process_avg's clamped definition verbatim, output pixel by output pixel
+// (avg_pixel_generic) -- one lane per row and one row of waves per frame.  Clamped loads alone would NOT reproduce the
+// definition: a pooling window that hangs over the edge by a whole chroma block would average a block made of the edge pixel
+// only, where the definition re-reads the clamped pixel's own (partly real) block.  Rows and output rows need no alignment:
+// gfx950 executes 16-byte global accesses at any 4-byte address (tools/ubench_unaligned.hip: 6.16-6.35 TB/s against 6.49
+// aligned, no mismatches).
 // ------------------------------------------------------------------------------------------------
-// arithmetic + stores of one already loaded 4 x TH tile
+// arithmetic + stores of one already loaded 4 x TH tile that lies inside the frame
 template <int ROUND, int FMT, int F, int HH, int VV, bool NT, int TH>
 __device__ __forceinline__ void avg_tile(const KArgs &a, const u32x4 (&p)[TH], gout_t out, int tr, int x4)
 {
     constexpr int NLOG = (HH == 4 ? 2 : HH == 2 ? 1 : 0) + (VV == 2 ? 1 : 0);
     constexpr int FLOG2 = (F == 8 ? 6 : F == 4 ? 4 : F == 2 ? 2 : 0);
-    {
-        uint32_t Y[TH][4], Cb[TH][4], Cr[TH][4];
+    const u16x2 qmask = {(unsigned short)a.mcb, (unsigned short)a.mcr};
+    uint32_t Y[TH][4];
+    u16x2 C[TH][4];
 #pragma unroll
-        for (int i = 0; i < TH; ++i) {
-            const uint32_t px[4] = {p[i].x, p[i].y, p[i].z, p[i].w};
+    for (int i = 0; i < TH; ++i) {
+        const uint32_t px[4] = {p[i].x, p[i].y, p[i].z, p[i].w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                Y[i][j] = fwd_y(px[j]);
-                fwd_c<ROUND>(px[j], Cb[i][j], Cr[i][j]);
-            }
+        for (int j = 0; j < 4; ++j) {
+            Y[i][j] = fwd_y(px[j]);
+            C[i][j] = fwd_c_pk<ROUND>(px[j]);
         }
-        // chroma stage: HH x VV block averages, written back to every pixel of the block
+    }
+    // chroma stage: HH x VV block averages, written back to every pixel of the block (sums <= 8 * 255: 16 bits hold them)
+    if (HH * VV > 1) {
+        const u16x2 half = {(HH * VV) >> 1, (HH * VV) >> 1};
 #pragma unroll
         for (int bi = 0; bi < TH; bi += VV) {
 #pragma unroll
             for (int bj = 0; bj < 4; bj += HH) {
-                uint32_t sb = 0, sr = 0;
+                u16x2 s = {0, 0};
 #pragma unroll
                 for (int i = 0; i < VV; ++i)
 #pragma unroll
-                    for (int j = 0; j < HH; ++j) { sb += Cb[bi + i][bj + j]; sr += Cr[bi + i][bj + j]; }
-                sb = (sb + ((HH * VV) >> 1)) >> NLOG;
-                sr = (sr + ((HH * VV) >> 1)) >> NLOG;
+                    for (int j = 0; j < HH; ++j) s += C[bi + i][bj + j];
+                s = (s + half) >> (unsigned short)NLOG;
 #pragma unroll
                 for (int i = 0; i < VV; ++i)
 #pragma unroll
-                    for (int j = 0; j < HH; ++j) { Cb[bi + i][bj + j] = sb; Cr[bi + i][bj + j] = sr; }
+                    for (int j = 0; j < HH; ++j) C[bi + i][bj + j] = s;
             }
         }
-        if (F <= 4) {
-            constexpr int FF = (F <= 4) ? F : 4;        // (keeps the F = 8 instantiation well-formed)
-            constexpr int NOX = 4 / FF, NOY = TH / FF;  // output pixels per tile
+    }
+    if (F <= 4) {
+        constexpr int FF = (F <= 4) ? F : 4;        // (keeps the F = 8 instantiation well-formed)
+        constexpr int NOX = 4 / FF, NOY = TH / FF;  // output pixels per tile
+        const u16x2 half = {(FF * FF) >> 1, (FF * FF) >> 1};
 #pragma unroll
-            for (int oi = 0; oi < NOY; ++oi) {
-                uint32_t o[NOX];
+        for (int oi = 0; oi < NOY; ++oi) {
+            uint32_t o[NOX];
 #pragma unroll
-                for (int oj = 0; oj < NOX; ++oj) {
-                    uint32_t sy = 0, sb = 0, sr = 0;
+            for (int oj = 0; oj < NOX; ++oj) {
+                uint32_t sy = 0;
+                u16x2 sc = {0, 0};                   // <= 16 * 255
 #pragma unroll
-                    for (int i = 0; i < FF; ++i)
+                for (int i = 0; i < FF; ++i)
 #pragma unroll
-                        for (int j = 0; j < FF; ++j) {
-                            sy += Y[oi * FF + i][oj * FF + j]; sb += Cb[oi * FF + i][oj * FF + j]; sr += Cr[oi * FF + i][oj * FF + j];
-                        }
-                    sy = ((sy + ((FF * FF) >> 1)) >> FLOG2) & a.my;
-                    sb = ((sb + ((FF * FF) >> 1)) >> FLOG2) & a.mcb;
-                    sr = ((sr + ((FF * FF) >> 1)) >> FLOG2) & a.mcr;
-                    o[oj] = finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr));
-                }
-                const gout_t op = out + (int64_t)(tr * NOY + oi) * a.op + x4 * NOX;
-                if (NOX == 4) { const u32x4 ov = {o[0], o[1 % NOX], o[2 % NOX], o[3 % NOX]}; st4<NT>(op, ov); }
-                else if (NOX == 2) { const u32x2 ov = {o[0], o[1 % NOX]}; st2<NT>(op, ov); }
-                else st1<NT>(op, o[0]);
+                    for (int j = 0; j < FF; ++j) { sy += Y[oi * FF + i][oj * FF + j]; sc += C[oi * FF + i][oj * FF + j]; }
+                sy = ((sy + ((FF * FF) >> 1)) >> FLOG2) & a.my;
+                sc = ((sc + half) >> (unsigned short)FLOG2) & qmask;
+                o[oj] = finish_y<FMT>(sy, chroma_term_q<FMT>(sc.x, sc.y));
             }
-        } else {
-            // F = 8: this lane's 4 x 8 half, then the neighbour's through a quad_perm [1,0,3,2] swap
-            uint32_t sy = 0, sb = 0, sr = 0;
-#pragma unroll
-            for (int i = 0; i < TH; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { sy += Y[i][j]; sb += Cb[i][j]; sr += Cr[i][j]; }
-            sy += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
-            sb += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sb, 0xB1, 0xF, 0xF, false);
-            sr += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sr, 0xB1, 0xF, 0xF, false);
-            if ((x4 & 1) == 0) {
-                sy = ((sy + 32) >> 6) & a.my;
-                sb = ((sb + 32) >> 6) & a.mcb;
-                sr = ((sr + 32) >> 6) & a.mcr;
-                st1<NT>(out + (int64_t)tr * a.op + (x4 >> 1), finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr)));
-            }
+            const int64_t oo = (int64_t)(tr * NOY + oi) * a.op + x4 * NOX;
+            if (NOX == 4) { const u32x4 ov = {o[0], o[1 % NOX], o[2 % NOX], o[3 % NOX]}; out4<NT>(a, out, oo, ov); }
+            else if (NOX == 2) { const u32x2 ov = {o[0], o[1 % NOX]}; out2<NT>(a, out, oo, ov); }
+            else out1<NT>(a, out, oo, o[0]);
         }
+    } else {
+        // F = 8: this lane's 4 x 8 half, then the neighbour's through a quad_perm [1,0,3,2] swap (sums <= 64 * 255 = 16 320)
+        uint32_t sy = 0;
+        u16x2 sc = {0, 0};
+#pragma unroll
+        for (int i = 0; i < TH; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sy += Y[i][j]; sc += C[i][j]; }
+        sy += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
+        const uint32_t scp = __builtin_bit_cast(uint32_t, sc);
+        sc += __builtin_bit_cast(u16x2, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)scp, 0xB1, 0xF, 0xF, false));
+        if ((x4 & 1) == 0) {
+            const u16x2 half = {32, 32};
+            sy = ((sy + 32) >> 6) & a.my;
+            sc = ((sc + half) >> (unsigned short)6) & qmask;
+            out1<NT>(a, out, (int64_t)tr * a.op + (x4 >> 1), finish_y<FMT>(sy, chroma_term_q<FMT>(sc.x, sc.y)));
+        }
+    }
+}
+
+// the output pixels a tile owns, for a tile the frame cuts: by the definition, with the bounds checked
+template <int ROUND, int FMT, int F, int VV, int TH>
+__device__ __forceinline__ void avg_tile_edge(const KArgs &a, gin_t in, gout_t out, int tr, int x4)
+{
+    if (F <= 4) {
+        constexpr int FF = (F <= 4) ? F : 4;
+        constexpr int NOX = 4 / FF, NOY = TH / FF;
+        for (int oi = 0; oi < NOY; ++oi)
+            for (int oj = 0; oj < NOX; ++oj) {
+                const int ro = tr * NOY + oi, co = x4 * NOX + oj;
+                if (ro < a.Ho && co < a.Wo) out1<false>(a, out, (int64_t)ro * a.op + co, avg_pixel_generic<ROUND, FMT, F_ARGB>(a, in, ro, co));
+            }
+    } else if ((x4 & 1) == 0) {
+        const int ro = tr, co = x4 >> 1;
+        if (ro < a.Ho && co < a.Wo) out1<false>(a, out, (int64_t)ro * a.op + co, avg_pixel_generic<ROUND, FMT, F_ARGB>(a, in, ro, co));
     }
 }
 
 // TILES column groups per lane, spaced by the block width: all TILES * TH loads are issued before the first
 // tile's arithmetic starts, so one tile's ~170 VALU ops overlap the other tiles' memory latency.
+// Needs W >= 4 (8 at F = 8) and H >= TH: at least one whole tile for the clamped loads to fall back on (select_rf).
 template <int ROUND, int FMT, int F, int HH, int VV, bool NT, int TILES = (F <= 2 ? 2 : 1)>
 __global__ void __launch_bounds__(256) k_avg(KArgs a)
 {
     constexpr int TH = (F > VV) ? F : VV;               // tile rows per lane
     pin_args(a);
-    const int W4 = a.W >> 2;
+    const int W4 = (a.W + 3) >> 2, W4f = a.W >> 2;      // tiles per tile row (the last one possibly cut), whole tiles
     const int x0 = blockIdx.x * (a.bdx * TILES) + threadIdx.x;
     if (x0 >= W4) return;
     const gin_t in = frame_in(a);
     const gout_t out = frame_out(a);
-    const int ntr = a.H / TH;
+    const int ntr = (a.H + TH - 1) / TH, ntrf = a.H / TH;
     for (int tr = blockIdx.y * a.bdy + threadIdx.y; tr < ntr; tr += a.row_step) {
         u32x4 p[TILES][TH];
+        const int trc = min(tr, ntrf - 1);                     // a cut tile loads a whole one (unused) instead of branching
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-            const int x4 = min(x0 + t * a.bdx, W4 - 1);        // clamp: out-of-row tiles re-read the last one
+            const int x4 = min(x0 + t * a.bdx, W4f - 1);       // clamp: out-of-row and cut tiles re-read the last whole one
 #pragma unroll
-            for (int i = 0; i < TH; ++i) p[t][i] = ld4<NT>(in + (int64_t)(tr * TH + i) * a.ip + 4 * x4);
+            for (int i = 0; i < TH; ++i) p[t][i] = in4<NT>(a, in, (int64_t)(trc * TH + i) * a.ip + 4 * x4);
         }
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
             const int x4 = x0 + t * a.bdx;
-            if (TILES == 1 || x4 < W4) avg_tile<ROUND, FMT, F, HH, VV, NT, TH>(a, p[t], out, tr, x4);
+            if (TILES == 1 || x4 < W4) {
+                // inside the frame?  F = 8: the PAIR of tiles that makes one output (the predicate is the same in both lanes)
+                const bool whole = tr < ntrf && (F == 8 ? (x4 | 1) < W4f : x4 < W4f);
+                if (whole) avg_tile<ROUND, FMT, F, HH, VV, NT, TH>(a, p[t], out, tr, x4);
+                else avg_tile_edge<ROUND, FMT, F, VV, TH>(a, in, out, tr, x4);
+            }
         }
     }
 }
 
-// Any shape: one output pixel per lane, clamped coordinates, orc_process_avg verbatim.
+// Any shape and a YCbCr input stream: one output pixel per lane.
 template <int ROUND, int FMT, int INFMT>
 __global__ void __launch_bounds__(256) k_avg_generic(KArgs a)
 {
@@ -595,34 +464,8 @@ __global__ void __launch_bounds__(256) k_avg_generic(KArgs a)
     if (co >= a.Wo) return;
     const gin_t in = frame_in(a);
     const gout_t out = frame_out(a);
-    const int h = a.hmask + 1, v = a.vmask + 1, f = a.f;
-    const int nlog = (h == 4 ? 2 : h == 2 ? 1 : 0) + (v == 2 ? 1 : 0);
-    const int flog2 = 2 * a.sc_shift;
-    for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += a.row_step) {
-        uint32_t sy = 0, sb = 0, sr = 0;
-        for (int i = 0; i < f; ++i) {
-            for (int j = 0; j < f; ++j) {
-                const int r = min(ro * f + i, a.H - 1), c = min(co * f + j, a.W - 1);
-                sy += in_y<ROUND, INFMT>(in[(int64_t)r * a.ip + c]);
-                const int r0 = r & ~a.vmask, c0 = c & ~a.hmask;
-                uint32_t ab = 0, ar = 0;
-                for (int ii = 0; ii < v; ++ii) {
-                    for (int jj = 0; jj < h; ++jj) {
-                        const int rr = min(r0 + ii, a.H - 1), cc = min(c0 + jj, a.W - 1);
-                        uint32_t cb, cr;
-                        in_c<ROUND, INFMT>(in[(int64_t)rr * a.ip + cc], cb, cr);
-                        ab += cb; ar += cr;
-                    }
-                }
-                sb += (ab + ((h * v) >> 1)) >> nlog;
-                sr += (ar + ((h * v) >> 1)) >> nlog;
-            }
-        }
-        sy = ((sy + ((f * f) >> 1)) >> flog2) & a.my;
-        sb = ((sb + ((f * f) >> 1)) >> flog2) & a.mcb;
-        sr = ((sr + ((f * f) >> 1)) >> flog2) & a.mcr;
-        out[(int64_t)ro * a.op + co] = finish_y<FMT>(sy, chroma_term_q<FMT>(sb, sr));
-    }
+    for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += a.row_step)
+        out1<false>(a, out, (int64_t)ro * a.op + co, avg_pixel_generic<ROUND, FMT, INFMT>(a, in, ro, co));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -655,9 +498,9 @@ __global__ void __launch_bounds__(256) k_generic(KArgs a)
             c_idx = (int64_t)(sro * a.f) * a.ip + sco * a.f;       // (counters above use the semantic W, addresses the pitch)
         }
         uint32_t cb, cr;
-        in_c<ROUND, INFMT>(in[c_idx], cb, cr);
-        const uint32_t y = in_y<ROUND, INFMT>(in[y_idx]) & a.my;
-        out[(int64_t)ro * a.op + co] = finish_y<FMT>(y, chroma_term_q<FMT>(cb & a.mcb, cr & a.mcr));
+        in_c<ROUND, INFMT>(in1<false>(a, in, c_idx), cb, cr);
+        const uint32_t y = in_y<ROUND, INFMT>(in1<false>(a, in, y_idx)) & a.my;
+        out1<false>(a, out, (int64_t)ro * a.op + co, finish_y<FMT>(y, chroma_term_q<FMT>(cb & a.mcb, cr & a.mcr)));
     }
 }
 
@@ -686,7 +529,7 @@ __device__ __forceinline__ void flatgen_body(const KArgs &a, gin_t in, gout_t ou
         const uint32_t ro = (uint32_t)(((uint64_t)j * a.mWo) >> a.kWo);           // j / Wo, exact for j < 2^31
         const uint32_t co = j - ro * (uint32_t)a.Wo;
         yo[k] = (int64_t)(ro * (uint32_t)a.f) * a.ip + co * (uint32_t)a.f;
-        px[k] = ld1<NT>(in + yo[k]);
+        px[k] = in1<NT>(a, in, yo[k]);
         oo[k] = (int64_t)ro * a.op + co;
         int r, d;
         if (a.s_first) {                                                          // counters over the decimated stream, width W
@@ -706,14 +549,14 @@ __device__ __forceinline__ void flatgen_body(const KArgs &a, gin_t in, gout_t ou
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         hp[k] = 0;
-        if (__builtin_amdgcn_ballot_w64(need[k]) != 0) hp[k] = ld1<false>(in + (need[k] ? ho[k] : yo[k]));
+        if (__builtin_amdgcn_ballot_w64(need[k]) != 0) hp[k] = in1<false>(a, in, need[k] ? ho[k] : yo[k]);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t nb = (uint32_t)__shfl((int)px[k], lane - dd[k], 64);       // all lanes take part
         if (!CHECK || i0 + (uint32_t)k * T < n) {
             const ChromaTerm t = chroma_term<ROUND, FMT>(need[k] ? hp[k] : nb, a.mcb, a.mcr);
-            st1<NT>(out + oo[k], finish<FMT>(px[k], a.my, t));
+            out1<NT>(a, out, oo[k], finish<FMT>(px[k], a.my, t));
         }
     }
 }
@@ -947,10 +790,13 @@ static void select_rf(csic_plan *pl)
     if (pl->p.sampling == CSIC_SAMPLING_AVG) {
         const int th = g.f > g.v ? g.f : g.v;
         const int tw = g.f == 8 ? 8 : 4;
-        if (!pl->force_generic && !ycc_in && !pl->no_vec && g.W % tw == 0 && g.H % th == 0) {
+        // any shape with at least one whole tile (pair of tiles at f = 8) and tile row: the frame's cut tiles take the definition's
+        // clamped form inside k_avg; variant 8 keeps the rule of rounds 1-3 (whole tiles only, everything else generic) for A/B
+        const bool whole = g.W % tw == 0 && g.H % th == 0;
+        if (!pl->force_generic && !ycc_in && !pl->no_vec && g.W >= tw && g.H >= th && (whole || pl->variant != 8)) {
             pl->fam = FAM_AVG;
             pl->fn = nt ? pick_avg<ROUND, FMT, true>(g.f, g.h, g.v) : pick_avg<ROUND, FMT, false>(g.f, g.h, g.v);
-            pl->units_per_row = g.W / 4;
+            pl->units_per_row = (g.W + 3) / 4;
             pl->k_per_lane = (g.f <= 2) ? 2 : 1;          // TILES of k_avg
             snprintf(pl->name, sizeof pl->name, "k_avg<%s,%s,f%d,h%d,v%d,%s>", rn, fn, g.f, g.h, g.v, ntn);
         } else {
@@ -1028,6 +874,11 @@ static void select_rf(csic_plan *pl)
 
 static void select(csic_plan *pl)
 {
+    if (pl->p.out_format == CSIC_FMT_PLANAR) {           // csic_planar.hip picks and names its kernels
+        pl->fam = FAM_GENERIC; pl->fn = nullptr; pl->units_per_row = pl->g.Wo; pl->k_per_lane = 1;
+        planar_kernel_name(pl, pl->name, sizeof pl->name);
+        return;
+    }
     const int r = pl->p.rounding, f = pl->p.out_format;
     if (r == R_FLOOR && f == F_ARGB) select_rf<R_FLOOR, F_ARGB>(pl);
     else if (r == R_FLOOR) select_rf<R_FLOOR, F_YCC>(pl);
@@ -1037,31 +888,11 @@ static void select(csic_plan *pl)
 
 static int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-// Resolves kernel, grid and arguments for `nframes` frames (<= 65535, the grid z limit) whose base pointers OR to
-// `align_bits`; the callers below fill in where the frames are.
-static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes, int32_t in_pitch, int32_t out_pitch, LaunchDesc *d)
+// The geometry half of the kernel arguments (what does not depend on the kernel family or the launch shape).
+void fill_base_args(const Geometry &g, int32_t ip, int32_t op, KArgs *pa)
 {
-    if (nframes <= 0 || nframes > 65535)
-        return set_error(CSIC_EINVAL_SIZE, "nframes per launch must be in 1..65535. Got %d", nframes);
-    const Geometry &g = pl->g;
-
-    Family fam = pl->fam;
-    KernelFn fn = pl->fn;
-    int units = pl->units_per_row, kpl = pl->k_per_lane, dec_hold = pl->dec_hold;
-    // The vector kernels need 16-byte aligned frame bases; otherwise take the 4-byte-access kernels.
-    const int32_t ip = in_pitch > 0 ? in_pitch : g.W, op = out_pitch > 0 ? out_pitch : g.Wo;
-    if (ip < g.W || op < g.Wo)
-        return set_error(CSIC_EINVAL_SIZE, "row pitch (%d, %d px) smaller than the frame width (%d, %d px)", ip, op, g.W, g.Wo);
-    const bool vec = (fam == FAM_F1X4 || fam == FAM_DEC2V1 || fam == FAM_DEC2V2 || fam == FAM_AVG);
-    if (vec && ((align_bits & 15u) || ((ip | op) & 3))) {
-        csic_plan tmp = *pl;
-        tmp.no_vec = 1;
-        select(&tmp);
-        fam = tmp.fam; fn = tmp.fn; units = tmp.units_per_row; kpl = tmp.k_per_lane; dec_hold = tmp.dec_hold;
-    }
-
-    KArgs &a = d->args;
-    a.in = nullptr; a.out = nullptr; a.in_tab = nullptr; a.out_tab = nullptr;
+    KArgs &a = *pa;
+    std::memset(&a, 0, sizeof a);
     a.W = g.W; a.H = g.H; a.Wo = g.Wo; a.Ho = g.Ho;
     a.last_sample_col = g.last_sample_col;
     a.my = g.mask_y; a.mcb = g.mask_cb; a.mcr = g.mask_cr;
@@ -1074,13 +905,46 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
     a.bc_col_in = (g.last_sample_col % g.Wo) * g.f;
     magic_div((uint32_t)g.W, &a.mW, &a.kW);
     magic_div((uint32_t)g.Wo, &a.mWo, &a.kWo);
+}
+
+// Resolves kernel, grid and arguments for `nframes` frames (<= 65535, the grid z limit) whose base pointers OR to
+// `align_bits`; the callers below fill in where the frames are.
+static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes, int32_t in_pitch, int32_t out_pitch, LaunchDesc *d)
+{
+    if (nframes <= 0 || nframes > 65535)
+        return set_error(CSIC_EINVAL_SIZE, "nframes per launch must be in 1..65535. Got %d", nframes);
+    if (pl->p.out_format == CSIC_FMT_PLANAR)
+        return set_error(CSIC_EINVAL_FORMAT, "planar plans go through csic_process_device / csic_process_batch_device / csic_process_host "
+                                              "only (no row pitches, frame graphs, pipelines, file pools or csic_multi)");
+    const Geometry &g = pl->g;
+
+    Family fam = pl->fam;
+    KernelFn fn = pl->fn;
+    int units = pl->units_per_row, kpl = pl->k_per_lane, dec_hold = pl->dec_hold;
+    // The vector kernels need 16-byte aligned frame bases; otherwise take the 4-byte-access kernels.
+    const int32_t ip = in_pitch > 0 ? in_pitch : g.W, op = out_pitch > 0 ? out_pitch : g.Wo;
+    if (ip < g.W || op < g.Wo)
+        return set_error(CSIC_EINVAL_SIZE, "row pitch (%d, %d px) smaller than the frame width (%d, %d px)", ip, op, g.W, g.Wo);
+    // (k_avg takes any 4-byte alignment: gfx950 executes its 16-byte accesses at any dword address, tools/ubench_unaligned.hip;
+    // the others keep the rule because their 4-byte fallbacks are as fast as a misaligned vector access would be)
+    const bool vec = (fam == FAM_F1X4 || fam == FAM_DEC2V1 || fam == FAM_DEC2V2);
+    if (vec && ((align_bits & 15u) || ((ip | op) & 3))) {
+        csic_plan tmp = *pl;
+        tmp.no_vec = 1;
+        select(&tmp);
+        fam = tmp.fam; fn = tmp.fn; units = tmp.units_per_row; kpl = tmp.k_per_lane; dec_hold = tmp.dec_hold;
+    }
+
+    KArgs &a = d->args;
+    fill_base_args(g, ip, op, &a);
 
     // Threads per block.  256 by default; k_dec takes two-wave blocks (128 threads) for a single frame of >= 64 MB whose rows
     // tile into full waves at that width: measured on one-frame-per-launch streams (profiles/r02_probe_block_shapes.log)
     // 8192x8192 f=2 32.48 -> 31.89 us, 16384x4096 32.56 -> 31.98, 8192x4096 17.44 -> 17.27, 6144x6144 19.38 -> 19.18,
     // 8192x8192 f=4 15.52 -> 15.37; no gain below ~64 MB (8192x2048: 9.88 / 9.88), none for batched launches, and a loss
     // where 128 lanes do not divide the row into full waves (7680x4320: 17.29 -> 17.93).  CSIC_TUNE_BLOCK_THREADS overrides.
-    const int rows = (fam == FAM_F1X4) ? g.H : (fam == FAM_AVG) ? g.H / (g.f > g.v ? g.f : g.v) : g.Ho;
+    const int avg_th = g.f > g.v ? g.f : g.v;
+    const int rows = (fam == FAM_F1X4) ? g.H : (fam == FAM_AVG) ? (g.H + avg_th - 1) / avg_th : g.Ho;
     const int lanes_x = (units + kpl - 1) / kpl;
     int tpb = 256;
     const bool forced = pl->block_threads == 64 || pl->block_threads == 128 || pl->block_threads == 256;
@@ -1200,6 +1064,13 @@ static int launch(csic_plan *pl, const void *d_in, void *d_out, int nframes, hip
     if (!pl) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
     if (nframes <= 0) return set_error(CSIC_EINVAL_SIZE, "nframes must be positive. Got %d", nframes);
     CSIC_DEVICE_SCOPE(pl->device);
+    if (pl->p.out_format == CSIC_FMT_PLANAR) {
+        if (in_pitch > 0 || out_pitch > 0)
+            return set_error(CSIC_EINVAL_FORMAT, "planar output takes packed input rows and its own plane layout: no row pitches");
+        const int st = planar_forward(pl, d_in, d_out, nframes, stream);
+        if (st == CSIC_OK) clear_error();
+        return st;
+    }
     for (int f0 = 0; f0 < nframes; f0 += 65535) {     // grid z limit
         const int nz = (nframes - f0 < 65535) ? nframes - f0 : 65535;
         LaunchDesc d;
@@ -1220,6 +1091,10 @@ int launch_on_stream(csic_plan *pl, const void *d_in, void *d_out, int nframes, 
     return launch(pl, d_in, d_out, nframes, stream);
 }
 int plan_device(const csic_plan *pl) { return pl->device; }
+const csic_params &plan_params(const csic_plan *pl) { return pl->p; }
+const Geometry &plan_geometry(const csic_plan *pl) { return pl->g; }
+int plan_variant(const csic_plan *pl) { return pl->variant; }
+bool plan_nontemporal(const csic_plan *pl) { return !pl->no_nt; }
 int64_t plan_algorithmic_bytes(const csic_plan *pl)
 {
     int64_t b = 0;
@@ -1229,6 +1104,11 @@ void plan_sizes(const csic_plan *pl, size_t *in_px, size_t *out_px)
 {
     *in_px = (size_t)pl->g.W * pl->g.H;
     *out_px = (size_t)pl->g.Wo * pl->g.Ho;
+    if (pl->p.out_format == CSIC_FMT_PLANAR) {           // what csic_process_host moves: the planar frame buffer, in 4-byte words
+        csic_planar_layout L;
+        planar_layout(pl->g, &pl->p, &L);
+        *out_px = (size_t)(L.frame_bytes / 4);
+    }
 }
 int32_t plan_width(const csic_plan *pl) { return pl->g.W; }
 void plan_out_dims(const csic_plan *pl, int32_t *wo, int32_t *ho)
@@ -1327,12 +1207,25 @@ int csic_process_pitched_device(csic_plan *plan, const void *d_in, int32_t in_pi
     return launch(plan, d_in, d_out, nframes, static_cast<hipStream_t>(hip_stream), in_pitch_px, out_pitch_px);
 }
 
+int csic_plan_preferred_pitch(const csic_plan *plan, int32_t *in_pitch_px, int32_t *out_pitch_px)
+{
+    if (!plan || !in_pitch_px || !out_pitch_px) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
+    const Geometry &g = plan->g;
+    // Rows that are a multiple of 8 KiB start in the same DRAM channel: pad them by 1 KiB (256 pixels).  The rule and its
+    // measurements: include/csic.h, tools/probe_pitch2.py, profiles/r04_probe_pitch.jsonl.
+    *in_pitch_px = (g.W % 2048 == 0) ? g.W + 256 : g.W;
+    *out_pitch_px = (g.Wo % 2048 == 0) ? g.Wo + 256 : g.Wo;
+    if (plan->p.out_format == CSIC_FMT_PLANAR) { *in_pitch_px = g.W; *out_pitch_px = g.Wo; }     // planar takes packed rows only
+    clear_error();
+    return CSIC_OK;
+}
+
 int csic_process_host(csic_plan *plan, const uint32_t *in, size_t in_px, uint32_t *out, size_t out_px)
 {
     if (!plan) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
     if (!in || !out) return set_error(CSIC_EINVAL_NULL, "host buffer is NULL");
-    const Geometry &g = plan->g;
-    const size_t need_in = (size_t)g.W * g.H, need_out = (size_t)g.Wo * g.Ho;
+    size_t need_in, need_out;
+    plan_sizes(plan, &need_in, &need_out);
     if (in_px != need_in || out_px != need_out)
         return set_error(CSIC_EINVAL_SIZE, "expected %zu input and %zu output pixels, got %zu and %zu",
                          need_in, need_out, in_px, out_px);

@@ -46,6 +46,8 @@ int csic_multi_create(const csic_params *p, const int32_t *devices, int32_t ndev
     if (ndev < 1 || ndev > 64) return set_error(CSIC_EINVAL_STRIPE, "ndev must be in 1..64. Got %d", ndev);
     int st = csic_validate(p);
     if (st != CSIC_OK) return st;
+    if (p->out_format == CSIC_FMT_PLANAR)
+        return set_error(CSIC_EINVAL_FORMAT, "csic_multi_* gathers packed row stripes: out_format must not be CSIC_FMT_PLANAR");
     csic_multi *m = new (std::nothrow) csic_multi();
     if (!m) return set_error(CSIC_ENOMEM, "out of host memory");
     m->params = *p;

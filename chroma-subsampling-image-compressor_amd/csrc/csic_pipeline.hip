@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "csic_hip_common.h"
+#include "csic_trace.h"
 
 struct csic_pipeline {
     struct Slot {
@@ -56,6 +57,8 @@ int csic_pipeline_create(csic_plan *plan, int32_t depth, csic_pipeline **out)
     if (!plan || !out) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
     *out = nullptr;
     if (depth < 1 || depth > 64) return set_error(CSIC_EINVAL_SIZE, "pipeline depth must be in 1..64. Got %d", depth);
+    if (plan_params(plan).out_format == CSIC_FMT_PLANAR)
+        return set_error(CSIC_EINVAL_FORMAT, "the host-frame pipeline moves packed pixels: the plan's out_format must not be CSIC_FMT_PLANAR");
     csic_pipeline *pp = new (std::nothrow) csic_pipeline();
     if (!pp) return set_error(CSIC_ENOMEM, "out of host memory");
     pp->plan = plan;
@@ -122,13 +125,17 @@ int csic_pipeline_submit(csic_pipeline *pp, int64_t *ticket)
         // The kernel streams the pinned host frame over PCIe itself and writes the result straight back:
         // input rows that hold no surviving pixel (r % f != 0) never cross the bus, and the read and
         // write directions are busy at the same time inside one launch.
+        trace::Range r("csic:launch_kernel_zero_copy");
         st = launch_on_stream(pp->plan, s.h_in, s.h_out, 1, s.stream);
         if (st != CSIC_OK) return st;
     } else {
-        HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, pp->in_px * 4, hipMemcpyHostToDevice, s.stream));
-        st = launch_on_stream(pp->plan, s.d_in, s.d_out, 1, s.stream);
-        if (st != CSIC_OK) return st;
-        HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, pp->out_px * 4, hipMemcpyDeviceToHost, s.stream));
+        { trace::Range r("csic:enqueue_h2d"); HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, pp->in_px * 4, hipMemcpyHostToDevice, s.stream)); }
+        {
+            trace::Range r("csic:launch_kernel");
+            st = launch_on_stream(pp->plan, s.d_in, s.d_out, 1, s.stream);
+            if (st != CSIC_OK) return st;
+        }
+        { trace::Range r("csic:enqueue_d2h"); HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, pp->out_px * 4, hipMemcpyDeviceToHost, s.stream)); }
     }
     HIP_TRY(hipEventRecord(s.done, s.stream));
     s.ticket = pp->next_ticket++;
@@ -147,7 +154,7 @@ int csic_pipeline_collect(csic_pipeline *pp, const uint32_t **host_out, int64_t 
     if (pp->pending == 0) return set_error(CSIC_EINVAL_SIZE, "no submitted frame to collect");
     CSIC_DEVICE_SCOPE(pp->device);
     csic_pipeline::Slot &s = pp->slots[pp->tail];
-    HIP_TRY(hipEventSynchronize(s.done));
+    { trace::Range r("csic:wait_gpu"); HIP_TRY(hipEventSynchronize(s.done)); }
     *host_out = s.h_out;
     if (ticket) *ticket = s.ticket;
     s.in_flight = false;          // the output buffer stays valid until this slot is submitted again

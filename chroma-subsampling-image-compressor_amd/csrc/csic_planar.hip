@@ -1,0 +1,487 @@
+// csic_planar.hip -- out_format = CSIC_FMT_PLANAR: the same pixel pipeline with a genuinely subsampled result (one Y byte
+// per output pixel, one Cb and one Cr byte per chroma SAMPLE POINT), and csic_reconstruct_device, its inverse.  The layout
+// and the reconstruct rule are defined in include/csic.h (csic_planar_layout); SURVEY.md 8 f3, VERDICT r03 item 4.
+//
+// Why it is reference-derivable although the reference never builds the format (ChromaSubsampler.scala:57-65 re-emits the held
+// chroma with every pixel; README.md:35-46 only describes the subsampled wire format): the packed YCbCr stream the reference
+// does produce is, by App. A.3, a pure function of Y at every position and Cb / Cr at the sample points -- the planar frame
+// stores exactly those, and reconstruct replays the hold (the in-row hold and the 4:x:0 "odd rows replay the last sample of
+// the row above" quirk), so  reconstruct(planar(x)) == packed(x)  bit for bit (tests/test_gpu_planar.py, against the oracle).
+//
+// Kernels (wave64; HBM-bound byte work, no LDS, no MFMA):
+//   k_planar_flat<ROUND, MODE, NT>  HOLD_DECIMATE, every order and shape.  Lanes over groups of 4 consecutive positions of
+//                      the OUTPUT stream, K = 4 groups per lane spaced by the block size (every load / store instruction of
+//                      a wave is contiguous in the stream): 4 Y bytes leave as one 4-byte store.
+//                        MODE 2  factor 1, W % 4 == 0: one 16-byte load per group; Cb / Cr of a group leave as one 4-, 2- or
+//                                1-byte store (h = 1, 2, 4); rows without sample points (4:x:0 odd rows) compute Y only.
+//                        MODE 1  module_width % 4 == 0 (a group never straddles chroma rows): 4-byte loads at stride f
+//                                (rows r % f != 0 are never read), the same packed chroma stores.
+//                        MODE 0  anything else (spatial before chroma with ragged widths): per-position chroma byte stores.
+//   k_planar_avg_f1<ROUND, HE, VE, NT>  AVG extension, factor 1, whole 4 x VE tiles: a lane owns a 4-pixel x VE-row tile
+//                      (VE 16-byte loads), so every h x v chroma block lies in its registers: true 4:2:2 / 4:2:0 / 4:1:1
+//                      box-filtered chroma -- what the north star's prose describes -- at 1.5-3 bytes per pixel out.
+//   k_planar_avg_gen<ROUND>  AVG, anything else: one output position per lane by the definition (avg_pixel_generic).
+//   k_recon<FMT, FAST, NT>  planar -> packed: 4 positions per lane, one 4-byte Y load, the chroma samples of the group as
+//                      one 4- / 2- / 1-byte load when module_width % 4 == 0 (FAST), per-position byte loads otherwise;
+//                      one 16-byte store.
+// Algorithmic bytes: input as for the packed path (4 * W * ceil(H / f), AVG: 4 * W * H) + csic_planar_layout.payload_bytes;
+// reconstruct: payload_bytes + 4 * n.
+#include <cstdio>
+#include <cstring>
+
+#include "csic_kernel_ops.h"
+
+namespace csic {
+
+struct PExtra {
+    uint8_t *planar;              // forward: destination frame buffers; reconstruct: source
+    uint32_t *packed;             // reconstruct: destination (n pixels per frame, back to back)
+    int64_t cb_off, cr_off, frame_bytes, n;
+    int32_t Wm, Wc, lhe, lve, replay_last;      // module width, samples per chroma row, log2 hold_h / hold_v
+    uint32_t mWm, kWm;                          // exact j / Wm (magic_div)
+    int32_t T;                                  // threads per block
+};
+
+typedef uint8_t CSIC_GLOBAL *gbyte_t;
+typedef const uint8_t CSIC_GLOBAL *gcbyte_t;
+typedef unsigned short CSIC_GLOBAL *gshort_t;
+typedef const unsigned short CSIC_GLOBAL *gcshort_t;
+
+#if defined(CSIC_DEBUG) && CSIC_DEBUG
+#define CSIC_PCHECK(e, off, nbytes) CSIC_CHECK((off) >= 0 && (int64_t)(off) + (nbytes) <= (e).frame_bytes)
+#else
+#define CSIC_PCHECK(e, off, nbytes) do { } while (0)
+#endif
+
+template <bool NT> __device__ __forceinline__ void pst1(const PExtra &e, gbyte_t base, int64_t off, uint32_t v)
+{
+    CSIC_PCHECK(e, off, 1); (void)e;
+    if (NT) __builtin_nontemporal_store((uint8_t)v, base + off); else base[off] = (uint8_t)v;
+}
+template <bool NT> __device__ __forceinline__ void pst2(const PExtra &e, gbyte_t base, int64_t off, uint32_t v)
+{
+    CSIC_PCHECK(e, off, 2); (void)e;
+    if (NT) __builtin_nontemporal_store((unsigned short)v, (gshort_t)(base + off)); else *(gshort_t)(base + off) = (unsigned short)v;
+}
+template <bool NT> __device__ __forceinline__ void pst4(const PExtra &e, gbyte_t base, int64_t off, uint32_t v)
+{
+    CSIC_PCHECK(e, off, 4); (void)e;
+    if (NT) __builtin_nontemporal_store(v, (gout_t)(base + off)); else *(gout_t)(base + off) = v;
+}
+__device__ __forceinline__ uint32_t pld1(const PExtra &e, gcbyte_t base, int64_t off) { CSIC_PCHECK(e, off, 1); (void)e; return base[off]; }
+__device__ __forceinline__ uint32_t pld2(const PExtra &e, gcbyte_t base, int64_t off) { CSIC_PCHECK(e, off, 2); (void)e; return *(gcshort_t)(base + off); }
+template <bool NT> __device__ __forceinline__ uint32_t pld4(const PExtra &e, gcbyte_t base, int64_t off)
+{
+    CSIC_PCHECK(e, off, 4); (void)e;
+    return NT ? __builtin_nontemporal_load((gin_t)(base + off)) : *(gin_t)(base + off);
+}
+
+__device__ __forceinline__ gbyte_t planar_frame(const PExtra &e) { return (gbyte_t)(uintptr_t)e.planar + (int64_t)blockIdx.z * e.frame_bytes; }
+
+// ------------------------------------------------------------------------------------------------
+// forward, HOLD_DECIMATE
+// ------------------------------------------------------------------------------------------------
+// input offset of output stream position j: decimated (ro, co) = (j / Wo, j % Wo) -> image (ro * f, co * f)
+__device__ __forceinline__ int64_t stream_in_off(const KArgs &a, uint32_t j)
+{
+    const uint32_t ro = (uint32_t)(((uint64_t)j * a.mWo) >> a.kWo);
+    const uint32_t co = j - ro * (uint32_t)a.Wo;
+    return (int64_t)(ro * (uint32_t)a.f) * a.ip + co * (uint32_t)a.f;
+}
+
+// one position on its own (the stream's ragged tail, and every position of MODE 0)
+template <int ROUND, bool NT>
+__device__ __forceinline__ void planar_one(const KArgs &a, const PExtra &e, gin_t in, gbyte_t fb, uint32_t j, uint32_t px, bool store_y)
+{
+    if (store_y) pst1<NT>(e, fb, (int64_t)j, fwd_y(px) & a.my);
+    const uint32_t r = (uint32_t)(((uint64_t)j * e.mWm) >> e.kWm), c = j - r * (uint32_t)e.Wm;
+    if ((c & ((1u << e.lhe) - 1u)) == 0 && (r & ((1u << e.lve) - 1u)) == 0) {          // a sample point emits its OWN chroma
+        uint32_t cb, cr;
+        fwd_c<ROUND>(px, cb, cr);
+        const int64_t k = (int64_t)(r >> e.lve) * e.Wc + (c >> e.lhe);
+        pst1<NT>(e, fb, e.cb_off + k, cb & a.mcb);
+        pst1<NT>(e, fb, e.cr_off + k, cr & a.mcr);
+    }
+    (void)in;
+}
+
+template <int ROUND, int MODE, int K, bool NT, bool CHECK>
+__device__ __forceinline__ void planar_flat_body(const KArgs &a, const PExtra &e, gin_t in, gbyte_t fb, uint32_t g0, uint32_t T, uint32_t ngroups)
+{
+    const uint32_t n = (uint32_t)e.n;
+    uint32_t px[K][4];
+    bool live[K], full[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t g = g0 + (uint32_t)k * T;
+        live[k] = !CHECK || g < ngroups;
+        const uint32_t gc = CHECK ? min(g, ngroups - 1) : g;                 // clamp instead of branching: the loads still issue back to back
+        const uint32_t j0 = 4u * gc;
+        full[k] = !CHECK || j0 + 3u < n;
+        if (MODE == 2) {
+            // factor 1, W % 4 == 0: the group is 4 consecutive pixels of one row (the stream IS the image)
+            const u32x4 v = in4<NT>(a, in, stream_in_off(a, j0));
+            px[k][0] = v.x; px[k][1] = v.y; px[k][2] = v.z; px[k][3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) px[k][q] = in1<NT>(a, in, stream_in_off(a, min(j0 + (uint32_t)q, n - 1u)));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (!live[k]) continue;
+        const uint32_t j0 = 4u * (g0 + (uint32_t)k * T);
+        if (CHECK && !full[k]) {                                             // the stream's ragged tail: position by position
+            for (uint32_t q = 0; q < 4u && j0 + q < n; ++q) planar_one<ROUND, NT>(a, e, in, fb, j0 + q, px[k][q], true);
+            continue;
+        }
+        const uint32_t y4 = (fwd_y(px[k][0]) & a.my) | ((fwd_y(px[k][1]) & a.my) << 8) | ((fwd_y(px[k][2]) & a.my) << 16) |
+                            ((fwd_y(px[k][3]) & a.my) << 24);
+        pst4<NT>(e, fb, (int64_t)j0, y4);
+        if (MODE == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) planar_one<ROUND, NT>(a, e, in, fb, j0 + (uint32_t)q, px[k][q], false);
+        } else {
+            // module_width % 4 == 0: the group sits in ONE chroma row at a column that is a multiple of 4
+            const uint32_t r = (uint32_t)(((uint64_t)j0 * e.mWm) >> e.kWm), c0 = j0 - r * (uint32_t)e.Wm;
+            if ((r & ((1u << e.lve) - 1u)) != 0) continue;                   // no sample point in this row (wave-uniform almost everywhere)
+            const int64_t k0 = (int64_t)(r >> e.lve) * e.Wc + (c0 >> e.lhe);
+            uint32_t cb[4], cr[4];
+            if (e.lhe == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { fwd_c<ROUND>(px[k][q], cb[q], cr[q]); cb[q] &= a.mcb; cr[q] &= a.mcr; }
+                pst4<NT>(e, fb, e.cb_off + k0, cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24));
+                pst4<NT>(e, fb, e.cr_off + k0, cr[0] | (cr[1] << 8) | (cr[2] << 16) | (cr[3] << 24));
+            } else if (e.lhe == 1) {
+                fwd_c<ROUND>(px[k][0], cb[0], cr[0]);
+                fwd_c<ROUND>(px[k][2], cb[2], cr[2]);
+                pst2<NT>(e, fb, e.cb_off + k0, (cb[0] & a.mcb) | ((cb[2] & a.mcb) << 8));
+                pst2<NT>(e, fb, e.cr_off + k0, (cr[0] & a.mcr) | ((cr[2] & a.mcr) << 8));
+            } else {
+                fwd_c<ROUND>(px[k][0], cb[0], cr[0]);
+                pst1<NT>(e, fb, e.cb_off + k0, cb[0] & a.mcb);
+                pst1<NT>(e, fb, e.cr_off + k0, cr[0] & a.mcr);
+            }
+        }
+    }
+}
+
+constexpr int PLANAR_K = 4;
+
+template <int ROUND, int MODE, bool NT>
+__global__ void __launch_bounds__(256) k_planar_flat(KArgs a, PExtra e)
+{
+    pin_args(a);
+    const uint32_t T = (uint32_t)e.T;
+    const uint32_t ngroups = (uint32_t)((e.n + 3) >> 2);
+    const uint32_t b0 = blockIdx.x * (T * PLANAR_K);
+    const gin_t in = frame_in(a);
+    const gbyte_t fb = planar_frame(e);
+    // whole block inside the stream AND no ragged tail in it: the straight-line path
+    if (b0 + T * PLANAR_K <= ngroups && (uint64_t)4 * (b0 + T * PLANAR_K) <= (uint64_t)e.n)
+        planar_flat_body<ROUND, MODE, PLANAR_K, NT, false>(a, e, in, fb, b0 + threadIdx.x, T, ngroups);
+    else
+        planar_flat_body<ROUND, MODE, PLANAR_K, NT, true>(a, e, in, fb, b0 + threadIdx.x, T, ngroups);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, AVG extension
+// ------------------------------------------------------------------------------------------------
+// factor 1, W % 4 == 0, H % VE == 0: a lane owns a 4-pixel x VE-row tile; K tiles per lane spaced by the block width
+template <int ROUND, int HE, int VE, bool NT>
+__global__ void __launch_bounds__(256) k_planar_avg_f1(KArgs a, PExtra e)
+{
+    constexpr int K = 2;
+    constexpr int NLOG = (HE == 4 ? 2 : HE == 2 ? 1 : 0) + (VE == 2 ? 1 : 0);
+    pin_args(a);
+    const int W4 = a.W >> 2;
+    const int x0 = blockIdx.x * (a.bdx * K) + threadIdx.x;
+    if (x0 >= W4) return;
+    const gin_t in = frame_in(a);
+    const gbyte_t fb = planar_frame(e);
+    const int ntr = a.H / VE;
+    const u16x2 qmask = {(unsigned short)a.mcb, (unsigned short)a.mcr};
+    for (int tr = blockIdx.y * a.bdy + threadIdx.y; tr < ntr; tr += a.row_step) {
+        u32x4 p[K][VE];
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const int x4 = min(x0 + t * a.bdx, W4 - 1);
+#pragma unroll
+            for (int i = 0; i < VE; ++i) p[t][i] = in4<NT>(a, in, (int64_t)(tr * VE + i) * a.ip + 4 * x4);
+        }
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const int x4 = x0 + t * a.bdx;
+            if (x4 >= W4) continue;
+            u16x2 C[VE][4];
+#pragma unroll
+            for (int i = 0; i < VE; ++i) {
+                const uint32_t px[4] = {p[t][i].x, p[t][i].y, p[t][i].z, p[t][i].w};
+                uint32_t y4 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { y4 |= (fwd_y(px[j]) & a.my) << (8 * j); C[i][j] = fwd_c_pk<ROUND>(px[j]); }
+                pst4<NT>(e, fb, (int64_t)(tr * VE + i) * a.W + 4 * x4, y4);
+            }
+            // HE x VE box averages: 4 / HE samples per tile
+            uint32_t cb = 0, cr = 0;
+            const u16x2 half = {(HE * VE) >> 1, (HE * VE) >> 1};
+#pragma unroll
+            for (int bj = 0; bj < 4; bj += HE) {
+                u16x2 s = {0, 0};
+#pragma unroll
+                for (int i = 0; i < VE; ++i)
+#pragma unroll
+                    for (int j = 0; j < HE; ++j) s += C[i][bj + j];
+                s = ((s + half) >> (unsigned short)NLOG) & qmask;
+                cb |= (uint32_t)s.x << (8 * (bj / HE));
+                cr |= (uint32_t)s.y << (8 * (bj / HE));
+            }
+            const int64_t k0 = (int64_t)tr * e.Wc + x4 * (4 / HE);
+            if (HE == 1) { pst4<NT>(e, fb, e.cb_off + k0, cb); pst4<NT>(e, fb, e.cr_off + k0, cr); }
+            else if (HE == 2) { pst2<NT>(e, fb, e.cb_off + k0, cb); pst2<NT>(e, fb, e.cr_off + k0, cr); }
+            else { pst1<NT>(e, fb, e.cb_off + k0, cb); pst1<NT>(e, fb, e.cr_off + k0, cr); }
+        }
+    }
+}
+
+// any factor, any shape: one output position per lane by the definition
+template <int ROUND>
+__global__ void __launch_bounds__(256) k_planar_avg_gen(KArgs a, PExtra e)
+{
+    pin_args(a);
+    const int co = blockIdx.x * a.bdx + threadIdx.x;
+    if (co >= a.Wo) return;
+    const gin_t in = frame_in(a);
+    const gbyte_t fb = planar_frame(e);
+    for (int ro = blockIdx.y * a.bdy + threadIdx.y; ro < a.Ho; ro += a.row_step) {
+        const uint32_t ycc = avg_pixel_generic<ROUND, F_YCC, F_ARGB>(a, in, ro, co);    // Y | Cb << 8 | Cr << 16, quantised
+        pst1<false>(e, fb, (int64_t)ro * a.Wo + co, ycc & 0xFFu);
+        if ((co & ((1 << e.lhe) - 1)) == 0 && (ro & ((1 << e.lve) - 1)) == 0) {           // module_width == Wo under AVG
+            const int64_t k = (int64_t)(ro >> e.lve) * e.Wc + (co >> e.lhe);
+            pst1<false>(e, fb, e.cb_off + k, (ycc >> 8) & 0xFFu);
+            pst1<false>(e, fb, e.cr_off + k, (ycc >> 16) & 0xFFu);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reconstruct: planar -> packed
+// ------------------------------------------------------------------------------------------------
+// chroma sample index of stream position (r, c) -- csic.h, csic_planar_layout
+__device__ __forceinline__ int64_t recon_index(const PExtra &e, uint32_t r, uint32_t c)
+{
+    if ((r & ((1u << e.lve) - 1u)) == 0 || !e.replay_last) return (int64_t)(r >> e.lve) * e.Wc + (c >> e.lhe);
+    return (int64_t)((r - 1u) >> e.lve) * e.Wc + (e.Wc - 1);          // ChromaSubsampler.scala:52-65: the last sample of the row above
+}
+
+template <int FMT, bool FAST, bool NT>
+__global__ void __launch_bounds__(256) k_recon(KArgs a, PExtra e)
+{
+    pin_args(a);
+    const uint32_t n = (uint32_t)e.n;
+    const uint32_t g = blockIdx.x * (uint32_t)e.T + threadIdx.x;
+    const uint32_t j0 = 4u * g;
+    if (j0 >= n) return;
+    const gcbyte_t fb = (gcbyte_t)planar_frame(e);
+    const gout_t out = (gout_t)(uintptr_t)e.packed + (int64_t)blockIdx.z * e.n;
+    (void)a;
+    if (j0 + 3u >= n || !FAST) {
+        // the stream's ragged tail, or groups that may straddle chroma rows: position by position
+        uint32_t o[4];
+        const uint32_t cnt = min(4u, n - j0);
+        for (uint32_t q = 0; q < cnt; ++q) {
+            const uint32_t j = j0 + q;
+            const uint32_t r = (uint32_t)(((uint64_t)j * e.mWm) >> e.kWm), c = j - r * (uint32_t)e.Wm;
+            const int64_t k = recon_index(e, r, c);
+            o[q] = finish_y<FMT>(pld1(e, fb, (int64_t)j), chroma_term_q<FMT>(pld1(e, fb, e.cb_off + k), pld1(e, fb, e.cr_off + k)));
+        }
+        if (cnt == 4u) { const u32x4 ov = {o[0], o[1], o[2], o[3]}; st4<NT>(out + j0, ov); }
+        else for (uint32_t q = 0; q < cnt; ++q) out[j0 + q] = o[q];
+        return;
+    }
+    // module_width % 4 == 0: the group lies in one chroma row at a column that is a multiple of 4
+    const uint32_t y4 = pld4<NT>(e, fb, (int64_t)j0);
+    const uint32_t r = (uint32_t)(((uint64_t)j0 * e.mWm) >> e.kWm), c0 = j0 - r * (uint32_t)e.Wm;
+    uint32_t cb[4], cr[4];
+    if ((r & ((1u << e.lve) - 1u)) != 0 && e.replay_last) {
+        const int64_t k = recon_index(e, r, c0);                            // one sample for the whole row
+        cb[0] = cb[1] = cb[2] = cb[3] = pld1(e, fb, e.cb_off + k);
+        cr[0] = cr[1] = cr[2] = cr[3] = pld1(e, fb, e.cr_off + k);
+    } else {
+        const int64_t k0 = (int64_t)(r >> e.lve) * e.Wc + (c0 >> e.lhe);
+        if (e.lhe == 0) {
+            const uint32_t b4 = pld4<false>(e, fb, e.cb_off + k0), r4 = pld4<false>(e, fb, e.cr_off + k0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { cb[q] = (b4 >> (8 * q)) & 0xFFu; cr[q] = (r4 >> (8 * q)) & 0xFFu; }
+        } else if (e.lhe == 1) {
+            const uint32_t b2 = pld2(e, fb, e.cb_off + k0), r2 = pld2(e, fb, e.cr_off + k0);
+            cb[0] = cb[1] = b2 & 0xFFu; cb[2] = cb[3] = b2 >> 8;
+            cr[0] = cr[1] = r2 & 0xFFu; cr[2] = cr[3] = r2 >> 8;
+        } else {
+            cb[0] = cb[1] = cb[2] = cb[3] = pld1(e, fb, e.cb_off + k0);
+            cr[0] = cr[1] = cr[2] = cr[3] = pld1(e, fb, e.cr_off + k0);
+        }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = finish_y<FMT>((y4 >> (8 * q)) & 0xFFu, chroma_term_q<FMT>(cb[q], cr[q]));
+    const u32x4 ov = {o[0], o[1], o[2], o[3]};
+    st4<NT>(out + j0, ov);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+using PlanarFn = void (*)(KArgs, PExtra);
+
+static int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+
+static void fill_extra(const csic_planar_layout &L, PExtra *e)
+{
+    std::memset(e, 0, sizeof *e);
+    e->cb_off = L.cb_offset; e->cr_off = L.cr_offset; e->frame_bytes = L.frame_bytes;
+    e->n = (int64_t)L.y_width * L.y_height;
+    e->Wm = L.module_width; e->Wc = L.chroma_width; e->lhe = ilog2(L.hold_h); e->lve = ilog2(L.hold_v); e->replay_last = L.replay_last;
+    magic_div((uint32_t)L.module_width, &e->mWm, &e->kWm);
+}
+
+// which forward kernel a plan takes: 0 = flat MODE 0, 1 = flat MODE 1, 2 = flat MODE 2, 3 = avg_f1, 4 = avg_gen
+static int forward_kind(const csic_plan *pl, const csic_planar_layout &L)
+{
+    const csic_params &p = plan_params(pl);
+    const Geometry &g = plan_geometry(pl);
+    const bool general = plan_variant(pl) == 9;                 // CSIC_TUNE_VARIANT 9: the general kernels (A/B, tests)
+    if (p.sampling == CSIC_SAMPLING_AVG)
+        return (!general && g.f == 1 && g.W % 4 == 0 && g.H % g.v == 0) ? 3 : 4;
+    if (general || L.module_width % 4 != 0) return 0;
+    return (g.f == 1 && g.W % 4 == 0) ? 2 : 1;
+}
+
+template <int ROUND, bool NT>
+static PlanarFn pick_forward(int kind, int he, int ve)
+{
+    switch (kind) {
+    case 0: return k_planar_flat<ROUND, 0, NT>;
+    case 1: return k_planar_flat<ROUND, 1, NT>;
+    case 2: return k_planar_flat<ROUND, 2, NT>;
+    case 3:
+        if (ve == 1) return he == 1 ? k_planar_avg_f1<ROUND, 1, 1, NT> : he == 2 ? k_planar_avg_f1<ROUND, 2, 1, NT> : k_planar_avg_f1<ROUND, 4, 1, NT>;
+        return he == 1 ? k_planar_avg_f1<ROUND, 1, 2, NT> : he == 2 ? k_planar_avg_f1<ROUND, 2, 2, NT> : k_planar_avg_f1<ROUND, 4, 2, NT>;
+    default: return k_planar_avg_gen<ROUND>;
+    }
+}
+
+void planar_kernel_name(const csic_plan *pl, char *buf, size_t len)
+{
+    csic_planar_layout L;
+    planar_layout(plan_geometry(pl), &plan_params(pl), &L);
+    const char *rn = plan_params(pl).rounding == CSIC_ROUND_FLOOR_HW ? "floor" : "trunc";
+    const char *nt = plan_nontemporal(pl) ? "nt" : "cached";
+    switch (forward_kind(pl, L)) {
+    case 0: snprintf(buf, len, "k_planar_flat<%s,general,h%d,v%d,%s>", rn, L.hold_h, L.hold_v, nt); break;
+    case 1: snprintf(buf, len, "k_planar_flat<%s,f%d,h%d,v%d,%s>", rn, plan_geometry(pl).f, L.hold_h, L.hold_v, nt); break;
+    case 2: snprintf(buf, len, "k_planar_flat<%s,f1x4,h%d,v%d,%s>", rn, L.hold_h, L.hold_v, nt); break;
+    case 3: snprintf(buf, len, "k_planar_avg_f1<%s,h%d,v%d,%s>", rn, L.hold_h, L.hold_v, nt); break;
+    default: snprintf(buf, len, "k_planar_avg_gen<%s,h%d,v%d>", rn, L.hold_h, L.hold_v); break;
+    }
+}
+
+static int launch_pk(PlanarFn fn, dim3 grid, dim3 block, KArgs a, PExtra e, hipStream_t stream)
+{
+    void *params[2] = {&a, &e};
+    HIP_TRY(hipLaunchKernel(reinterpret_cast<const void *>(fn), grid, block, params, 0, stream));
+    return CSIC_OK;
+}
+
+int planar_forward(const csic_plan *pl, const void *d_in, void *d_planar, int nframes, hipStream_t stream)
+{
+    if (!d_in || !d_planar) return set_error(CSIC_EINVAL_NULL, "device buffer is NULL");
+    if (((uintptr_t)d_planar & 255u) || ((uintptr_t)d_in & 3u))
+        return set_error(CSIC_EINVAL_SIZE, "a planar frame buffer must be 256-byte aligned (and the input 4-byte aligned)");
+    const csic_params &p = plan_params(pl);
+    const Geometry &g = plan_geometry(pl);
+    csic_planar_layout L;
+    planar_layout(g, &p, &L);
+    const int kind = forward_kind(pl, L);
+    const bool nt = plan_nontemporal(pl);
+    const bool floor_r = p.rounding == CSIC_ROUND_FLOOR_HW;
+    PlanarFn fn = floor_r ? (nt ? pick_forward<R_FLOOR, true>(kind, L.hold_h, L.hold_v) : pick_forward<R_FLOOR, false>(kind, L.hold_h, L.hold_v))
+                          : (nt ? pick_forward<R_TRUNC, true>(kind, L.hold_h, L.hold_v) : pick_forward<R_TRUNC, false>(kind, L.hold_h, L.hold_v));
+    for (int f0 = 0; f0 < nframes; f0 += 65535) {            // grid z limit
+        const int nz = nframes - f0 < 65535 ? nframes - f0 : 65535;
+        KArgs a;
+        fill_base_args(g, g.W, g.Wo, &a);
+        a.in = static_cast<const uint32_t *>(d_in) + (int64_t)f0 * a.in_frame_px;
+        PExtra e;
+        fill_extra(L, &e);
+        e.planar = static_cast<uint8_t *>(d_planar) + (int64_t)f0 * L.frame_bytes;
+        dim3 grid, block;
+        if (kind <= 2) {
+            const int64_t ngroups = (e.n + 3) / 4;
+            e.T = 256;
+            block = dim3(256, 1, 1);
+            grid = dim3((unsigned)((ngroups + 256 * PLANAR_K - 1) / (256 * PLANAR_K)), 1, (unsigned)nz);
+            a.bdx = 256; a.bdy = 1; a.row_step = 1;
+        } else {
+            // row-tiled kernels: lanes along x (tiles of 4 pixels for avg_f1 with 2 tiles per lane, output pixels for avg_gen)
+            const int lanes_x = kind == 3 ? (g.W / 4 + 1) / 2 : g.Wo;
+            const int rows = kind == 3 ? g.H / g.v : g.Ho;
+            int bx = 1;
+            while (bx < lanes_x && bx < 256) bx <<= 1;
+            const int by = 256 / bx;
+            unsigned gy = (unsigned)((rows + by - 1) / by);
+            if (gy > 65535u) gy = 65535u;
+            block = dim3(bx, by, 1);
+            grid = dim3((unsigned)((lanes_x + bx - 1) / bx), gy, (unsigned)nz);
+            a.bdx = bx; a.bdy = by; a.row_step = (int32_t)gy * by;
+            e.T = 256;
+        }
+        const int st = launch_pk(fn, grid, block, a, e, stream);
+        if (st != CSIC_OK) return st;
+    }
+    return CSIC_OK;
+}
+
+} // namespace csic
+
+using namespace csic;
+
+extern "C" int csic_reconstruct_device(csic_plan *plan, const void *d_planar, void *d_out, int32_t nframes, int32_t out_format,
+                                       void *hip_stream)
+{
+    if (!plan) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
+    if (!d_planar || !d_out) return set_error(CSIC_EINVAL_NULL, "device buffer is NULL");
+    if (nframes <= 0) return set_error(CSIC_EINVAL_SIZE, "nframes must be positive. Got %d", nframes);
+    if (out_format != CSIC_FMT_ARGB8888 && out_format != CSIC_FMT_YCBCR888X)
+        return set_error(CSIC_EINVAL_FORMAT, "csic_reconstruct_device writes ARGB8888(0) or YCBCR888X(1). Got %d", out_format);
+    if (((uintptr_t)d_planar & 255u) || ((uintptr_t)d_out & 15u))
+        return set_error(CSIC_EINVAL_SIZE, "a planar frame buffer must be 256-byte aligned and the packed output 16-byte aligned");
+    const csic_params &p = plan_params(plan);
+    const Geometry &g = plan_geometry(plan);
+    csic_planar_layout L;
+    planar_layout(g, &p, &L);
+    CSIC_DEVICE_SCOPE(plan_device(plan));
+    const bool fast = L.module_width % 4 == 0 && plan_variant(plan) != 9;
+    const bool nt = plan_nontemporal(plan);
+    PlanarFn fn;
+    if (out_format == CSIC_FMT_ARGB8888)
+        fn = fast ? (nt ? k_recon<F_ARGB, true, true> : k_recon<F_ARGB, true, false>) : (nt ? k_recon<F_ARGB, false, true> : k_recon<F_ARGB, false, false>);
+    else
+        fn = fast ? (nt ? k_recon<F_YCC, true, true> : k_recon<F_YCC, true, false>) : (nt ? k_recon<F_YCC, false, true> : k_recon<F_YCC, false, false>);
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    for (int f0 = 0; f0 < nframes; f0 += 65535) {
+        const int nz = nframes - f0 < 65535 ? nframes - f0 : 65535;
+        KArgs a;
+        fill_base_args(g, g.W, g.Wo, &a);
+        PExtra e;
+        fill_extra(L, &e);
+        e.planar = const_cast<uint8_t *>(static_cast<const uint8_t *>(d_planar)) + (int64_t)f0 * L.frame_bytes;
+        e.packed = static_cast<uint32_t *>(d_out) + (int64_t)f0 * e.n;
+        e.T = 256;
+        const int64_t ngroups = (e.n + 3) / 4;
+        const int st = launch_pk(fn, dim3((unsigned)((ngroups + 255) / 256), 1, (unsigned)nz), dim3(256, 1, 1), a, e, stream);
+        if (st != CSIC_OK) return st;
+    }
+    clear_error();
+    return CSIC_OK;
+}

@@ -36,6 +36,7 @@
 #endif
 
 #include "csic_internal.h"
+#include "csic_trace.h"
 
 using namespace csic;
 
@@ -525,8 +526,8 @@ int writer_threads(int asked)
 {
     if (asked > 0) return asked > 64 ? 64 : asked;
     if (const char *e = std::getenv("CSIC_PNG_THREADS")) { const int v = std::atoi(e); if (v > 0) return v > 64 ? 64 : v; }
-    const unsigned hw = std::thread::hardware_concurrency();
-    return hw == 0 ? 4 : hw > 16 ? 16 : (int)hw;
+    const int budget = host_cpu_budget();                  // affinity mask and cgroup quota, not the CPUs the machine shows
+    return budget > 16 ? 16 : budget;
 }
 
 } // namespace

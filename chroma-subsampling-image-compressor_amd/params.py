@@ -45,6 +45,7 @@ class Sampling(enum.IntEnum):
 class PixelFormat(enum.IntEnum):
     ARGB8888 = N.FMT_ARGB8888
     YCBCR888X = N.FMT_YCBCR888X
+    PLANAR = N.FMT_PLANAR          # out_format only: Y plane + Cb / Cr planes at the chroma sample points (csic_planar_layout)
 
 
 def make_c_params(width, height, a, b, yq, cbq, crq, sf, ops, rounding=Rounding.FLOOR_HW,

@@ -89,6 +89,7 @@ typedef enum csic_status {
 
 #define CSIC_FMT_ARGB8888  0
 #define CSIC_FMT_YCBCR888X 1
+#define CSIC_FMT_PLANAR    2   /* out_format only: Y plane + Cb / Cr planes at the chroma sample points (csic_planar_layout) */
 
 /* ---- parameters ---------------------------------------------------------------------------------
  * Field-for-field the constructor list of
@@ -105,7 +106,7 @@ typedef struct csic_params {
     int32_t op[3];                       /* permutation of CSIC_OP_{SPATIAL,QUANT,CHROMA}             */
     int32_t rounding;                    /* CSIC_ROUND_*                                              */
     int32_t sampling;                    /* CSIC_SAMPLING_HOLD_DECIMATE (reference) or CSIC_SAMPLING_AVG  */
-    int32_t in_format, out_format;       /* CSIC_FMT_*                                                */
+    int32_t in_format, out_format;       /* CSIC_FMT_* (CSIC_FMT_PLANAR: out_format only)             */
     int32_t strict_divisible;            /* 1 = enforce ImageProcessorParams' divisibility require()  */
 } csic_params;
 
@@ -154,6 +155,54 @@ int  csic_stripe_halo(const csic_params *p, int32_t nranks, int32_t rank, const 
                       int32_t *proc_row0, int32_t *proc_nrows, int32_t *halo_above, int32_t *tail_below,
                       int32_t *out_row0, int32_t *out_nrows);
 
+/* ---- planar, genuinely subsampled output (out_format = CSIC_FMT_PLANAR) ------------------------------------------
+ * Every packed output of the path is 4 bytes per pixel whatever the chroma mode: ChromaSubsampler re-emits the held Cb / Cr
+ * with every pixel (ChromaSubsampler.scala:57-65), so nothing the reference produces is smaller than its input -- its README
+ * describes the subsampled wire format (README.md:35-46), its code never builds it.  This format
+ * stores each value the stream really carries ONCE: a Y plane with one byte per output pixel and two chroma planes with one
+ * byte per chroma SAMPLE POINT.  4:2:0 at factor 1: 1.5 bytes per pixel instead of 4.
+ *
+ * Definition, on the output stream o[j], j = 0 .. n-1 (n = out_width * out_height, row-major), with the chroma stage's
+ * counters as the output sees them -- c = j mod module_width, r = j div module_width:
+ *     position j is a sample point  <=>  c % hold_h == 0  and  r % hold_v == 0
+ *     sample index  k(j) = (r / hold_v) * chroma_width + c / hold_h,     chroma_width = ceil(module_width / hold_h)
+ *     Y[j] = o[j].Y for every j;     Cb[k(j)] = o[j].Cb,  Cr[k(j)] = o[j].Cr  for every sample point j
+ *   (module_width, hold_h, hold_v) follow from where the chroma stage sits:
+ *     chroma before spatial, factor 1 : (W,  h, v)               -- the image's own 4:a:b grid
+ *     chroma before spatial, factor f : (Wo, max(1, h / f), 1)   -- decimation keeps every f-th column of the held stream
+ *     spatial before chroma           : (W,  h, v) over the DECIMATED stream: the chroma counters wrap at the FULL width
+ *                                       (ImageCompressorTop.scala:52-58), so one chroma row spans f decimated rows and the
+ *                                       last one may be partial (chroma_samples < chroma_width * chroma_height)
+ *     CSIC_SAMPLING_AVG               : (Wo, max(1, h / f), max(1, v / f)), replay_last = 0
+ * Values are what the packed YCbCr output holds at those positions (after the quantiser, in either rounding).
+ *
+ * csic_reconstruct_device is the inverse: planar -> packed ARGB (through YCbCrUtils.ycbcr2rgb, as the reference's harness
+ * does per pixel, ImageCompressorTopApp.scala:118) or packed YCbCr.  Position j takes Y[j] and the chroma sample
+ *     k(j)                                                      on rows r % hold_v == 0 (c / hold_h floors),
+ *     ((r - 1) / hold_v) * chroma_width + chroma_width - 1      on the other rows when replay_last = 1: the reference's
+ *                                                               4:x:0 hold replays the LAST sample of the row above for a
+ *                                                               whole row (ChromaSubsampler.scala:52-65),
+ *     (r / hold_v) * chroma_width + c / hold_h                  on the other rows when replay_last = 0 (AVG: plain box).
+ * For every parameter set  reconstruct(planar(x)) == the packed output of the same parameters, bit for bit: under
+ * HOLD_DECIMATE that pins the planar path to the reference exactly as far as the packed path is pinned; under AVG to
+ * oracle/csic_oracle.c:orc_process_avg -- no reference parity by construction.
+ *
+ * Buffer: ONE allocation per frame, planes at 256-byte aligned offsets; frame k of a batch at k * frame_bytes.  Planes are
+ * tightly packed (no row padding).  Bytes of a chroma plane beyond chroma_samples are never written. */
+typedef struct csic_planar_layout {
+    int32_t y_width, y_height;            /* = csic_out_dims                                                        */
+    int32_t chroma_width, chroma_height;  /* samples per chroma row, chroma rows                                    */
+    int32_t module_width;                 /* row length of the chroma counters over the output stream               */
+    int32_t hold_h, hold_v;               /* one sample per hold_h positions, on every hold_v-th chroma row          */
+    int32_t replay_last;                  /* 1: rows without samples replay the last sample of the row above (HOLD)  */
+    int64_t chroma_samples;               /* samples per chroma plane that carry data                               */
+    int64_t y_offset, cb_offset, cr_offset; /* byte offsets of the planes inside a frame's buffer                   */
+    int64_t frame_bytes;                  /* bytes per frame buffer (multiple of 256)                               */
+    int64_t payload_bytes;                /* y_width * y_height + 2 * chroma_samples: what the format really stores */
+} csic_planar_layout;
+/* usable without a GPU; p->out_format need not be CSIC_FMT_PLANAR (the layout of "these parameters, planar") */
+int  csic_planar_layout_of(const csic_params *p, csic_planar_layout *layout);
+
 const char *csic_strerror(int status);
 const char *csic_last_error(void);       /* thread-local; "" when the last call succeeded */
 
@@ -173,7 +222,8 @@ const char *csic_plan_kernel_name(const csic_plan *plan);
 
 /* Tuning knobs for A/B measurements; a knob the selected kernel does not have is ignored.
  *   CSIC_TUNE_VARIANT : kernel-family specific variant index (0 = default; 1, 2 = the 16-byte f = 2 kernels, 4 = k_dec for
- *                       f = 1, 5 = k_dec instead of k_decflat on rows that do not tile into whole blocks / waves, 6 = k_decflat wherever it applies, 7 = the one-pixel-per-lane k_generic instead of k_flatgen)
+ *                       f = 1, 5 = k_dec instead of k_decflat on rows that do not tile into whole blocks / waves, 6 = k_decflat wherever it applies, 7 = the one-pixel-per-lane k_generic instead of k_flatgen,
+ *                       8 = AVG: the tile kernel only for frames of whole tiles, as in rounds 1-3, 9 = planar: the general kernels instead of the factor-1 fast paths)
  *   CSIC_TUNE_FORCE_GENERIC : 1 = always use the one-thread-per-pixel generic kernel
  *   CSIC_TUNE_NONTEMPORAL   : 1 (default) = non-temporal loads/stores for the frame stream, 0 = cached
  *   CSIC_TUNE_NO_VECTOR     : 1 = never use the 16-byte-per-lane kernels
@@ -206,8 +256,26 @@ int  csic_process_batch_device(csic_plan *plan, const void *d_in, void *d_out, i
 int  csic_process_pitched_device(csic_plan *plan, const void *d_in, int32_t in_pitch_px, void *d_out,
                                  int32_t out_pitch_px, int32_t nframes, void *hip_stream);
 
+/* With out_format = CSIC_FMT_PLANAR, d_out of csic_process_device / csic_process_batch_device is a planar frame buffer of
+ * csic_planar_layout.frame_bytes bytes per frame (256-byte aligned).  Row pitches, frame graphs, the host-frame pipeline,
+ * the file pools and csic_multi_* take packed formats only (CSIC_EINVAL_FORMAT otherwise).
+ *
+ * csic_reconstruct_device: `nframes` planar frames of `plan`'s parameters (the plan may have any out_format: only its
+ * parameters matter) -> packed pixels, out_format = CSIC_FMT_ARGB8888 or CSIC_FMT_YCBCR888X, out_width * out_height per
+ * frame back to back; asynchronous on `hip_stream`, no allocation, capturable. */
+int  csic_reconstruct_device(csic_plan *plan, const void *d_planar, void *d_out, int32_t nframes, int32_t out_format,
+                             void *hip_stream);
+
+/* Row pitches, in pixels, at which frames of this plan stream fastest when the CALLER lays them out
+ * (csic_process_pitched_device): the width itself unless padding the rows is measured to pay.  Frames whose packed rows are
+ * a multiple of 8 KiB -- 2048-, 4096-, 8192-pixel rows -- start every row in the same DRAM channel; 256 pixels (1 KiB) of
+ * padding per row spread them (8192x8192: f = 2 78 -> 81-83 %, f = 8 75-77 -> 78-80 % of the HBM roofline; 16- and 64-pixel
+ * pads break the rows' 128-byte alignment and lose).  Packed rows remain the default of every entry point and the layout
+ * of the headline measurement; this only tells a caller that owns its surfaces what to allocate. */
+int  csic_plan_preferred_pitch(const csic_plan *plan, int32_t *in_pitch_px, int32_t *out_pitch_px);
+
 /* Convenience synchronous host path: H2D + kernel + D2H through plan-owned staging buffers.
- * in_px must equal width*height and out_px out_width*out_height. */
+ * in_px must equal width*height and out_px out_width*out_height (planar: frame_bytes / 4). */
 int  csic_process_host(csic_plan *plan, const uint32_t *in, size_t in_px, uint32_t *out, size_t out_px);
 
 /* Synthetic frame generator of SURVEY.md 8(d), on the device:

@@ -371,6 +371,97 @@ long orc_process_closed_mt(const orc_params *p, const uint32_t *in, uint32_t *ou
 }
 
 /* ------------------------------------------------------------------------- */
+/* planar, subsampled form of the output stream (include/csic.h, CSIC_FMT_PLANAR) */
+/* ------------------------------------------------------------------------- */
+/* The reference never builds this format (ChromaSubsampler.scala:57-65 re-emits the held chroma with every
+ * pixel; README.md:35-46 only describes it).  What pins it to the reference all the same: the planes hold
+ * nothing but values of the reference's OWN output stream -- Y at every position, Cb / Cr at the positions
+ * where the chroma stage, as seen from the output, is at a sample point -- and orc_planar_reconstruct below is
+ * ChromaSubsampler's latch (ChromaSubsampler.scala:29-65) replayed over them, so
+ *     orc_planar_reconstruct(orc_planar_from_stream(s)) == s
+ * for every stream s that orc_process_stream emits (tests/test_oracle_planar.py checks exactly that, for all
+ * six orders).  Which counters the output sees:
+ *   chroma before spatial, f = 1 : the image's own: row length W, holds h x v
+ *   chroma before spatial, f > 1 : the decimator keeps image columns co * f of rows ro * f: every kept row is a
+ *                                  sample row (f is even, v <= 2) and kept column co * f is a sample point iff
+ *                                  (co * f) % h == 0, i.e. co % max(1, h / f) == 0: row length Wo, holds max(1, h/f) x 1
+ *   spatial before chroma        : the stage runs on the decimated stream with its counters wrapping at the
+ *                                  FULL width (ImageCompressorTop.scala:52-58): row length W, holds h x v
+ *   AVG extension                : chroma blocks h x v pooled f x f: constant over max(1,h/f) x max(1,v/f) output pixels */
+int orc_planar_layout_of(const orc_params *p, int avg, orc_planar_layout *L)
+{
+    if (orc_validate(p) != 0) return -1;
+    int32_t wo, ho; orc_out_dims(p, &wo, &ho);
+    const int h = 4 / p->chroma_a, v = (p->chroma_b == 0) ? 2 : 1, f = p->factor;
+    L->y_width = wo; L->y_height = ho;
+    if (avg) {
+        L->module_width = wo; L->hold_h = h > f ? h / f : 1; L->hold_v = v > f ? v / f : 1; L->replay_last = 0;
+    } else if (f == 1 || spatial_before_chroma(p)) {
+        L->module_width = p->width; L->hold_h = h; L->hold_v = v; L->replay_last = 1;
+    } else {
+        L->module_width = wo; L->hold_h = h > f ? h / f : 1; L->hold_v = 1; L->replay_last = 1;
+    }
+    const int64_t n = (int64_t)wo * ho;
+    const int64_t rows = (n + L->module_width - 1) / L->module_width;
+    L->chroma_width = (L->module_width + L->hold_h - 1) / L->hold_h;
+    L->chroma_height = (int32_t)((rows + L->hold_v - 1) / L->hold_v);
+    int64_t cnt = 0;                       /* counted, not computed: one per sample point of the stream */
+    for (int64_t r = 0; r < rows; r += L->hold_v) {
+        const int64_t len = (r == rows - 1) ? n - r * L->module_width : L->module_width;
+        cnt += (len + L->hold_h - 1) / L->hold_h;
+    }
+    L->chroma_samples = cnt;
+    return 0;
+}
+
+/* ycc: the n = y_width * y_height packed output pixels (Y | Cb << 8 | Cr << 16) in stream order.  Samples are
+ * appended in the order the stream meets them.  Returns the number of chroma samples written. */
+long orc_planar_from_stream(const orc_planar_layout *L, const uint32_t *ycc, uint8_t *y, uint8_t *cb, uint8_t *cr)
+{
+    const int64_t n = (int64_t)L->y_width * L->y_height;
+    int64_t c = 0, r = 0, k = 0;          /* the chroma stage's column / row counters over the output stream */
+    for (int64_t j = 0; j < n; ++j) {
+        y[j] = (uint8_t)(ycc[j] & 0xFF);
+        if (c % L->hold_h == 0 && r % L->hold_v == 0) {
+            cb[k] = (uint8_t)((ycc[j] >> 8) & 0xFF);
+            cr[k] = (uint8_t)((ycc[j] >> 16) & 0xFF);
+            ++k;
+        }
+        if (++c == L->module_width) { c = 0; ++r; }
+    }
+    return (long)k;
+}
+
+/* planes -> packed stream.  replay_last: ChromaSubsampler's latch -- a sample point loads the next sample, every
+ * other position re-emits the latched one (so a row without sample points replays the last sample of the row
+ * above, ChromaSubsampler.scala:52-65).  Otherwise (AVG): each sample covers its hold_h x hold_v box. */
+long orc_planar_reconstruct(const orc_planar_layout *L, const uint8_t *y, const uint8_t *cb, const uint8_t *cr, int fmt, uint32_t *out)
+{
+    const int64_t n = (int64_t)L->y_width * L->y_height;
+    int64_t c = 0, r = 0, k = 0;
+    int last_cb = 0, last_cr = 0;         /* RegInit(0.U), ChromaSubsampler.scala:34-35 */
+    for (int64_t j = 0; j < n; ++j) {
+        int vcb, vcr;
+        if (L->replay_last) {
+            if (c % L->hold_h == 0 && r % L->hold_v == 0) { last_cb = cb[k]; last_cr = cr[k]; ++k; }
+            vcb = last_cb; vcr = last_cr;
+        } else {
+            const int64_t kk = (r / L->hold_v) * L->chroma_width + c / L->hold_h;
+            vcb = cb[kk]; vcr = cr[kk];
+        }
+        if (fmt == ORC_FMT_YCC) {
+            out[j] = (uint32_t)y[j] | ((uint32_t)vcb << 8) | ((uint32_t)vcr << 16);
+        } else {
+            int rr, gg, bb;
+            orc_ycbcr2rgb(y[j], vcb, vcr, &rr, &gg, &bb);
+            out[j] = 0xFF000000u | ((uint32_t)rr << 16) | ((uint32_t)gg << 8) | (uint32_t)bb;
+        }
+        if (++c == L->module_width) { c = 0; ++r; }
+    }
+    return (long)n;
+}
+
+/* ------------------------------------------------------------------------- */
 /* per-stage helpers for the KAT tests                                         */
 /* ------------------------------------------------------------------------- */
 

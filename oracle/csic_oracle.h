@@ -87,6 +87,19 @@ long orc_process_avg(const orc_params *p, const uint32_t *in, uint32_t *out);
 /* Closed form, output rows split over `nthreads` POSIX threads (CPU baseline on all host cores). */
 long orc_process_closed_mt(const orc_params *p, const uint32_t *in, uint32_t *out, int nthreads);
 
+/* ---- planar, subsampled form of the output stream (csic.h CSIC_FMT_PLANAR) -- */
+/* Y at every output position, Cb / Cr at the positions where the chroma stage -- as the OUTPUT sees its
+ * counters -- is at a sample point; see csic_oracle.c for the derivation and for what pins it. */
+typedef struct orc_planar_layout {
+    int32_t y_width, y_height, chroma_width, chroma_height;
+    int32_t module_width, hold_h, hold_v, replay_last;
+    int64_t chroma_samples;
+} orc_planar_layout;
+int  orc_planar_layout_of(const orc_params *p, int avg, orc_planar_layout *L);
+long orc_planar_from_stream(const orc_planar_layout *L, const uint32_t *ycc, uint8_t *y, uint8_t *cb, uint8_t *cr);
+long orc_planar_reconstruct(const orc_planar_layout *L, const uint8_t *y, const uint8_t *cb, const uint8_t *cr,
+                            int fmt, uint32_t *out);
+
 /* ---- per-stage helpers on YCbCr streams (used by the KAT tests) ----------- */
 /* Chroma sample-and-hold on a stream of n (Y,Cb,Cr) triples, module width/height
  * W,H: ChromaSubsampler.scala:37-65 == ChromaSubsamplerImageSpec.scala:45-78. */

@@ -35,6 +35,13 @@ class _Params(C.Structure):
     ]
 
 
+class PlanarLayout(C.Structure):
+    """orc_planar_layout (csic_oracle.h): the planar, subsampled form of the output stream."""
+    _fields_ = [("y_width", C.c_int32), ("y_height", C.c_int32), ("chroma_width", C.c_int32), ("chroma_height", C.c_int32),
+                ("module_width", C.c_int32), ("hold_h", C.c_int32), ("hold_v", C.c_int32), ("replay_last", C.c_int32),
+                ("chroma_samples", C.c_int64)]
+
+
 @dataclass
 class OracleParams:
     width: int
@@ -106,6 +113,13 @@ def lib() -> C.CDLL:
         L.orc_spatial_indices.restype = C.c_long
         L.orc_synth_frame.argtypes = [u32p, C.c_int64, C.c_int64, C.c_uint32]
         L.orc_synth_frame.restype = None
+        u8p = C.POINTER(C.c_uint8)
+        L.orc_planar_layout_of.argtypes = [C.POINTER(_Params), C.c_int, C.POINTER(PlanarLayout)]
+        L.orc_planar_layout_of.restype = C.c_int
+        L.orc_planar_from_stream.argtypes = [C.POINTER(PlanarLayout), u32p, u8p, u8p, u8p]
+        L.orc_planar_from_stream.restype = C.c_long
+        L.orc_planar_reconstruct.argtypes = [C.POINTER(PlanarLayout), u8p, u8p, u8p, C.c_int, u32p]
+        L.orc_planar_reconstruct.restype = C.c_long
         _lib = L
     return _lib
 
@@ -196,6 +210,39 @@ def spatial_indices(W: int, H: int, f: int) -> np.ndarray:
     idx = np.empty(cap, dtype=np.int64)
     n = lib().orc_spatial_indices(W, H, f, idx.ctypes.data_as(C.POINTER(C.c_int64)))
     return idx[:n]
+
+
+def planar_layout(p: OracleParams, avg: bool = False) -> PlanarLayout:
+    lay = PlanarLayout()
+    if lib().orc_planar_layout_of(C.byref(p.c()), 1 if avg else 0, C.byref(lay)) != 0:
+        raise ValueError("invalid parameters")
+    return lay
+
+
+def planar(p: OracleParams, argb: np.ndarray, avg: bool = False):
+    """The planar form of the oracle's own output stream: (layout, Y (Ho, Wo) uint8, Cb, Cr flat uint8 in sample order).
+    The stream comes from orc_process_stream (AVG: orc_process_avg) with out_format = YCC."""
+    from dataclasses import replace
+    ycc = process(replace(p, out_format=FMT_YCC), argb, form="avg" if avg else "stream").reshape(-1)
+    lay = planar_layout(p, avg)
+    n = lay.y_width * lay.y_height
+    y = np.empty(n, dtype=np.uint8)
+    cb = np.empty(max(1, lay.chroma_samples), dtype=np.uint8)
+    cr = np.empty(max(1, lay.chroma_samples), dtype=np.uint8)
+    u8 = C.POINTER(C.c_uint8)
+    k = lib().orc_planar_from_stream(C.byref(lay), _u32(np.ascontiguousarray(ycc)), y.ctypes.data_as(u8), cb.ctypes.data_as(u8), cr.ctypes.data_as(u8))
+    if k != lay.chroma_samples:
+        raise RuntimeError(f"the stream holds {k} sample points, the layout says {lay.chroma_samples}")
+    return lay, y.reshape(lay.y_height, lay.y_width), cb[:k], cr[:k]
+
+
+def planar_reconstruct(lay: PlanarLayout, y: np.ndarray, cb: np.ndarray, cr: np.ndarray, fmt: int = FMT_ARGB) -> np.ndarray:
+    """Planes -> packed (Ho, Wo) uint32: ChromaSubsampler's latch replayed over the samples (AVG: box replication)."""
+    u8 = C.POINTER(C.c_uint8)
+    yy, bb, rr = (np.ascontiguousarray(a, dtype=np.uint8).reshape(-1) for a in (y, cb, cr))
+    out = np.empty(lay.y_width * lay.y_height, dtype=np.uint32)
+    lib().orc_planar_reconstruct(C.byref(lay), yy.ctypes.data_as(u8), bb.ctypes.data_as(u8), rr.ctypes.data_as(u8), fmt, _u32(out))
+    return out.reshape(lay.y_height, lay.y_width)
 
 
 def synth_frame(npix: int, first_index: int = 0, seed: int = 20250629) -> np.ndarray:

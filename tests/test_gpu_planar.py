@@ -1,0 +1,235 @@
+"""out_format = CSIC_FMT_PLANAR on the GPU (csic_planar.hip): the planar planes against the oracle's planar form of the
+reference stream, csic_reconstruct_device against the packed oracle output, and the identity
+    reconstruct(planar(x)) == packed(x)
+that pins the format to the reference as far as the packed path is pinned (tests/test_oracle_planar.py shows the same on the
+CPU for the oracle's own streams).  Bit-exact (byte work): every comparison is np.array_equal / torch.equal."""
+import ctypes as C
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_png_rgb
+
+pytestmark = pytest.mark.gpu
+
+ORDERS = list(itertools.permutations((1, 2, 3)))
+CSQ = (3, 1, 2)
+MODES = [(4, 4), (2, 2), (2, 0), (1, 1), (4, 0), (1, 0)]
+
+with open(os.path.join(GOLDEN, "manifest.json")) as _fh:
+    _GOLDENS = json.load(_fh)["goldens"]
+
+
+@pytest.fixture(scope="module")
+def csic():
+    import csic_amd
+    assert csic_amd._native.lib().csic_device_count() >= 1
+    return csic_amd
+
+
+def _plan(csic, W, H, a, b, bits, f, op, rounding=0, fmt=2, avg=False):
+    cp = csic.make_c_params(W, H, a, b, *bits, f, op, rounding=rounding, out_format=fmt,
+                            sampling=csic.Sampling.AVG if avg else csic.Sampling.HOLD_DECIMATE)
+    return csic.Plan(cp, 0)
+
+
+def _op(orc, W, H, a, b, bits, f, op, rounding=0, fmt=0):
+    return orc.OracleParams(width=W, height=H, chroma_a=a, chroma_b=b, y_bits=bits[0], cb_bits=bits[1], cr_bits=bits[2],
+                            factor=f, op=op, rounding=rounding, out_format=fmt)
+
+
+def _check_one(csic, oracle, W, H, a, b, bits, f, op, rounding, avg, argb, variants=(0, 9)):
+    import torch
+    N = csic._native
+    form = "avg" if avg else "stream"
+    lay_o, y_o, cb_o, cr_o = oracle.planar(_op(oracle, W, H, a, b, bits, f, op, rounding), argb, avg=avg)
+    want_argb = oracle.process(_op(oracle, W, H, a, b, bits, f, op, rounding, 0), argb, form=form)
+    want_ycc = oracle.process(_op(oracle, W, H, a, b, bits, f, op, rounding, 1), argb, form=form)
+    d_in = torch.from_numpy(argb.view(np.int32)).cuda()
+    names = set()
+    with _plan(csic, W, H, a, b, bits, f, op, rounding, avg=avg) as pl:
+        lay = pl.planar_layout
+        for variant in variants:
+            pl.tune(N.TUNE_VARIANT, variant)
+            names.add(pl.kernel_name.split("<")[0] + ("*" if variant else ""))
+            buf = torch.full((lay.frame_bytes,), 0xEE, dtype=torch.uint8, device="cuda:0")
+            pl.process_device(d_in, buf)
+            y, cb, cr = pl.split_planar(buf.cpu().numpy())
+            tag = (pl.kernel_name, W, H, a, b, bits, f, op, rounding, avg, variant)
+            assert np.array_equal(y, y_o), tag
+            assert np.array_equal(cb, cb_o) and np.array_equal(cr, cr_o), tag
+            for fmt, want in ((N.FMT_ARGB8888, want_argb), (N.FMT_YCBCR888X, want_ycc)):
+                got = pl.reconstruct_device(buf, out_format=fmt).cpu().numpy().view(np.uint32)
+                assert np.array_equal(got, want), tag + (fmt,)
+        pl.tune(N.TUNE_VARIANT, 0)
+        # the host path moves the same planar frame buffer
+        yh, cbh, crh = pl.split_planar(pl.process_host(argb))
+        assert np.array_equal(yh, y_o) and np.array_equal(cbh, cb_o) and np.array_equal(crh, cr_o)
+    return names
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_planar_random_shapes_vs_oracle(csic, oracle, seed):
+    rng = np.random.default_rng(9100 + seed)
+    seen = set()
+    for _ in range(110):
+        W, H = int(rng.integers(1, 97)), int(rng.integers(1, 41))
+        r = rng.random()
+        if r < 0.35:
+            W = (W + 7) // 8 * 8
+        elif r < 0.5:
+            W, H = (W + 3) // 4 * 4, (H + 1) // 2 * 2
+        a, b = MODES[int(rng.integers(0, 6))]
+        bits = tuple(int(x) for x in rng.integers(1, 9, 3))
+        f = int(rng.choice([1, 1, 2, 4, 8]))
+        op = ORDERS[int(rng.integers(0, 6))]
+        rounding = int(rng.integers(0, 2))
+        argb = rng.integers(0, 1 << 32, W * H, dtype=np.uint32)
+        seen |= _check_one(csic, oracle, W, H, a, b, bits, f, op, rounding, False, argb)
+    assert "k_planar_flat" in seen and "k_planar_flat*" in seen
+
+
+def test_planar_avg_random_shapes_vs_oracle(csic, oracle):
+    rng = np.random.default_rng(9200)
+    seen = set()
+    for _ in range(120):
+        W, H = int(rng.integers(1, 80)), int(rng.integers(1, 40))
+        if rng.random() < 0.6:
+            W, H = (W + 3) // 4 * 4, (H + 1) // 2 * 2
+        a, b = MODES[int(rng.integers(0, 6))]
+        bits = tuple(int(x) for x in rng.integers(1, 9, 3))
+        f = int(rng.choice([1, 1, 1, 2, 4, 8]))
+        argb = rng.integers(0, 1 << 32, W * H, dtype=np.uint32)
+        seen |= _check_one(csic, oracle, W, H, a, b, bits, f, CSQ, int(rng.integers(0, 2)), True, argb)
+    assert {"k_planar_avg_f1", "k_planar_avg_gen"} <= seen
+
+
+@pytest.mark.parametrize("W,H", [(256, 64), (1920, 16), (1000, 12), (4096, 8), (1028, 10), (36, 6)])
+def test_planar_every_mode_kernel_and_order(csic, oracle, W, H):
+    """Every chroma mode x factor x order class on shapes that take each forward kernel (16-byte loads at factor 1, strided loads
+    with module_width % 4 == 0, the general kernel) and both reconstruct kernels."""
+    argb = oracle.synth_frame(W * H, W * 3 + H)
+    for (a, b), f, op in itertools.product(MODES, (1, 2, 4, 8), (CSQ, (1, 3, 2), (2, 1, 3))):
+        _check_one(csic, oracle, W, H, a, b, (8, 7, 6), f, op, 0, False, argb)
+    for (a, b), f in itertools.product(MODES, (1, 2, 8)):
+        _check_one(csic, oracle, W, H, a, b, (8, 8, 8), f, CSQ, 1, True, argb)
+
+
+def test_planar_reproduces_the_chroma_goldens(csic, oracle, input_images):
+    """The reference's committed chroma images (ChromaSubsamplerImageSpec.scala:229, TRUNC_SW; 16x16, 128x128, 512x512) through
+    planar -> reconstruct on the GPU."""
+    import torch
+    n = 0
+    for e in _GOLDENS:
+        if e["rounding"] == "IDENTITY" or e["factor"] != 1 or e["bits"] != [8, 8, 8]:
+            continue
+        rgb = input_images[e["input"]]
+        h, w = rgb.shape[:2]
+        rounding = 1 if e["rounding"] == "TRUNC_SW" else 0
+        with _plan(csic, w, h, e["chroma_a"], e["chroma_b"], (8, 8, 8), 1, e["op"], rounding) as pl:
+            d_in = torch.from_numpy(oracle.rgb_to_argb(rgb).view(np.int32)).cuda()
+            buf = pl.process_device(d_in)
+            got = oracle.argb_to_rgb(pl.reconstruct_device(buf).cpu().numpy().view(np.uint32))
+            lay = pl.planar_layout
+            assert lay.payload_bytes == w * h + 2 * lay.chroma_samples
+        assert np.array_equal(got, load_png_rgb(os.path.join(GOLDEN, e["file"]))), e["name"]
+        n += 1
+    assert n >= 10
+
+
+def test_planar_batches_and_buffer_hygiene(csic, oracle):
+    """Batched launches (frame k at k * frame_bytes), and nothing outside the planes' payload is written."""
+    import torch
+    W, H, n = 200, 26, 5
+    argb = oracle.synth_frame(n * W * H, 5)
+    d_in = torch.from_numpy(argb.view(np.int32)).cuda()
+    for (a, b, f, op, avg) in ((2, 0, 1, CSQ, False), (2, 0, 2, (1, 3, 2), False), (1, 1, 2, CSQ, False), (2, 0, 1, CSQ, True), (2, 2, 4, CSQ, True)):
+        with _plan(csic, W, H, a, b, (8, 8, 8), f, op, avg=avg) as pl:
+            lay = pl.planar_layout
+            buf = torch.full((n, lay.frame_bytes), 0xA7, dtype=torch.uint8, device="cuda:0")
+            pl.process_device(d_in, buf, nframes=n)
+            host = buf.cpu().numpy()
+            out = pl.reconstruct_device(buf, nframes=n).cpu().numpy().view(np.uint32)
+            for k in range(n):
+                fr = argb[k * W * H:(k + 1) * W * H]
+                lo, y_o, cb_o, cr_o = oracle.planar(_op(oracle, W, H, a, b, (8, 8, 8), f, op), fr, avg=avg)
+                y, cb, cr = pl.split_planar(host[k])
+                assert np.array_equal(y, y_o) and np.array_equal(cb, cb_o) and np.array_equal(cr, cr_o), (k, a, b, f, op, avg)
+                want = oracle.process(_op(oracle, W, H, a, b, (8, 8, 8), f, op), fr, form="avg" if avg else "stream")
+                assert np.array_equal(out[k], want), (k, a, b, f, op, avg)
+                nn = lay.y_width * lay.y_height
+                untouched = np.ones(lay.frame_bytes, dtype=bool)
+                untouched[:nn] = False
+                untouched[lay.cb_offset:lay.cb_offset + lay.chroma_samples] = False
+                untouched[lay.cr_offset:lay.cr_offset + lay.chroma_samples] = False
+                assert (host[k][untouched] == 0xA7).all(), (k, a, b, f, op, avg)
+
+
+def test_planar_full_size_identity_and_bytes(csic, oracle):
+    """BASELINE's 8192x8192 frame at factor 1, 4:2:0: reconstruct(planar(x)) == packed(x) on the device, for the reference's hold and
+    for the AVG extension; the planar frame is 1.5 bytes per pixel."""
+    import torch
+    N = csic._native
+    W = H = 8192
+    d_in = torch.empty(W * H, dtype=torch.int32, device="cuda:0")
+    sh = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N.check(N.lib().csic_synth_frame_device(C.c_void_p(d_in.data_ptr()), d_in.numel(), 0, 20250629, sh))
+    for avg in (False, True):
+        with _plan(csic, W, H, 2, 0, (3, 3, 2), 1, CSQ, avg=avg) as pl, _plan(csic, W, H, 2, 0, (3, 3, 2), 1, CSQ, fmt=0, avg=avg) as packed:
+            lay = pl.planar_layout
+            assert lay.payload_bytes == W * H * 3 // 2 and pl.algorithmic_bytes == 4 * W * H + W * H * 3 // 2
+            buf = pl.process_device(d_in)
+            back = pl.reconstruct_device(buf)
+            want = packed.process_device(d_in)
+            assert torch.equal(back.reshape(-1), want.reshape(-1)), (avg, pl.kernel_name)
+            assert pl.kernel_name.startswith("k_planar_avg_f1" if avg else "k_planar_flat<floor,f1x4"), pl.kernel_name
+        del buf, back, want
+    # a decimating plan: chroma before spatial at factor 2 keeps one sample per output pixel (3 bytes instead of 4)
+    with _plan(csic, W, H, 2, 0, (8, 8, 8), 2, CSQ) as pl, _plan(csic, W, H, 2, 0, (8, 8, 8), 2, CSQ, fmt=0) as packed:
+        assert pl.planar_layout.payload_bytes == 3 * (W // 2) * (H // 2)
+        assert torch.equal(pl.reconstruct_device(pl.process_device(d_in)).reshape(-1), packed.process_device(d_in).reshape(-1))
+
+
+def test_planar_is_refused_where_packed_pixels_are_expected(csic, oracle):
+    import torch
+    N = csic._native
+    lib = N.lib()
+    with _plan(csic, 64, 16, 2, 0, (8, 8, 8), 1, CSQ) as pl:
+        d_in = torch.zeros(64 * 16, dtype=torch.int32, device="cuda:0")
+        d_out = torch.zeros(pl.planar_layout.frame_bytes, dtype=torch.uint8, device="cuda:0")
+        with pytest.raises(csic.IllegalArgumentException, match="planar"):
+            pin, pout, h = (C.c_void_p * 1)(C.c_void_p(d_in.data_ptr())), (C.c_void_p * 1)(C.c_void_p(d_out.data_ptr())), C.c_void_p()
+            N.check(lib.csic_frame_graph_create_ex(pl._h, pin, pout, 1, 0, N.FRAME_GRAPH_FUSED, C.byref(h)))
+        with pytest.raises(csic.IllegalArgumentException, match="pitch"):
+            N.check(lib.csic_process_pitched_device(pl._h, C.c_void_p(d_in.data_ptr()), 64, C.c_void_p(d_out.data_ptr()), 64, 1, None))
+        with pytest.raises(csic.IllegalArgumentException, match="PLANAR"):
+            csic.FramePipeline(pl, depth=1)
+        with pytest.raises(csic.IllegalArgumentException):          # a misaligned planar buffer
+            N.check(lib.csic_process_device(pl._h, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr() + 4), None))
+        with pytest.raises(csic.IllegalArgumentException):
+            N.check(lib.csic_reconstruct_device(pl._h, C.c_void_p(d_out.data_ptr()), C.c_void_p(d_in.data_ptr()), 1, N.FMT_PLANAR, None))
+        assert pl.preferred_pitch == (64, 64)
+    with pytest.raises(csic.IllegalArgumentException):
+        csic.MultiDeviceCompressor(csic.make_c_params(64, 16, 2, 0, 8, 8, 8, 1, CSQ, out_format=csic.PixelFormat.PLANAR), [0])
+
+
+def test_preferred_pitch_rule(csic):
+    """csic_plan_preferred_pitch: rows that are a multiple of 8 KiB get 1 KiB of padding, everything else stays packed; the
+    padded layout gives the same pixels."""
+    import torch
+    for (W, f, want) in ((8192, 2, (8448, 4352)), (4096, 1, (4352, 4352)), (3840, 4, (3840, 960)), (1000, 2, (1000, 500)), (2048, 8, (2304, 256))):
+        with _plan(csic, W, 16, 2, 0, (8, 8, 8), f, CSQ, fmt=0) as pl:
+            assert pl.preferred_pitch == want, (W, f, pl.preferred_pitch)
+    W, H, f = 8192, 24, 2
+    with _plan(csic, W, H, 2, 0, (8, 8, 8), f, CSQ, fmt=0) as pl:
+        ip, op = pl.preferred_pitch
+        d_in = torch.randint(-2**31, 2**31 - 1, (H, W), dtype=torch.int32, device="cuda:0")
+        padded = torch.zeros((H, ip), dtype=torch.int32, device="cuda:0")
+        padded[:, :W] = d_in
+        out_p = torch.zeros((pl.out_height, op), dtype=torch.int32, device="cuda:0")
+        pl.process_device_pitched(padded.reshape(-1), ip, out_p.reshape(-1), op)
+        want = pl.process_device(d_in.reshape(-1).contiguous())
+        assert torch.equal(out_p[:, :pl.out_width], want)
