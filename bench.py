@@ -189,8 +189,18 @@ def verify_against_oracle(wl, order, avg, keep, torch):
     from oracle import oracle as orc
     W, H, a, b, bits, f, _ = CONFIGS[wl.args.config]
     rows = wl.stripe_rows
-    if wl.pad or wl.row0 != 0 or getattr(wl, "planar", False):
-        return {"vs": "oracle", "frames": 0, "equal": None, "skipped": "padded rows / a stripe that does not start at row 0 / planar output"}
+    if wl.pad or wl.row0 != 0:
+        return {"vs": "oracle", "frames": 0, "equal": None, "skipped": "padded rows / a stripe that does not start at row 0"}
+    if getattr(wl, "planar", False):
+        # planar: the three planes of ring slot 0 against the oracle's planar form of ITS stream for the same frame
+        lay = wl.plan.planar_layout
+        y, cb, cr = wl.plan.split_planar(wl.outs[0][:lay.frame_bytes // 4].cpu().numpy())
+        p = orc.OracleParams(width=W, height=rows, chroma_a=a, chroma_b=b, y_bits=bits[0], cb_bits=bits[1], cr_bits=bits[2], factor=f, op=tuple(order))
+        _, y_o, cb_o, cr_o = orc.planar(p, orc.synth_frame(W * rows, 0), avg=avg)
+        equal = bool(np.array_equal(y, y_o) and np.array_equal(cb, cb_o) and np.array_equal(cr, cr_o))
+        return {"vs": "oracle (planar form of " + ("orc_process_avg" if avg else "orc_process_stream") + ")", "frames": 1, "equal": equal,
+                "pixels": int(y.size), "chroma_samples": int(cb.size),
+                "what": f"the Y / Cb / Cr planes of ring slot 0 as the timed launches left them ({W}x{rows}, {lay.payload_bytes} payload bytes), rank 0, untimed"}
     got = wl.outs[0][:wl.out_px].cpu().numpy().view(np.uint32)
     if keep and keep.get("out") is not None and rows == H:
         want, form = keep["out"], keep["form"]
@@ -343,7 +353,7 @@ def _inject(rank, issue, phase):
 class Workload:
     """One rank's share of one scaling mode: its stripe, plan, ring of device frames and the step function."""
 
-    def __init__(self, args, csic, torch, dev, dev_index, world, rank, scaling, issue="serial"):
+    def __init__(self, args, csic, torch, dev, dev_index, world, rank, scaling, issue="serial", preferred_pitch=False):
         """issue: how the steps reach the GPU --
         "serial": one eager launch per step on the launch stream (N = 1 headline: the roofline contract);
         "hip"   : the same launches from a frame graph, CSIC_FRAME_GRAPH_HIP (hipGraph chains ordered with the stream);
@@ -361,8 +371,10 @@ class Workload:
         self.W, self.H, self.fps, self.scaling = W, H, fps, scaling
         gH = H * world if scaling == "weak" else H
         self.global_rows = gH
-        sampling = csic.Sampling.AVG if args.config in AVG_CONFIGS else csic.Sampling.HOLD_DECIMATE
+        sampling = csic.Sampling.AVG if (args.config in AVG_CONFIGS or args.config.endswith("_avg")) else csic.Sampling.HOLD_DECIMATE
         order = SCQ if args.order == "scq" else CSQ
+        self.planar = args.config in PLANAR_CONFIGS
+        out_format = csic.PixelFormat.PLANAR if self.planar else csic.PixelFormat.ARGB8888
         gparams = csic.make_c_params(W, gH, a, b, *bits, f, order, sampling=sampling)
         r0, nr, o0, on = (C.c_int32() for _ in range(4))
         parts, part = (args.stripe_of, 0) if (args.stripe_of > 1 and world == 1) else (world, rank)
@@ -371,7 +383,7 @@ class Workload:
         if self.stripe_rows == 0:
             raise RuntimeError(f"rank {part}: empty stripe ({gH} rows over {parts} ranks)")
         _inject(rank, issue, "create")
-        self.plan = csic.Plan(csic.make_c_params(W, self.stripe_rows, a, b, *bits, f, order, sampling=sampling), dev_index)
+        self.plan = csic.Plan(csic.make_c_params(W, self.stripe_rows, a, b, *bits, f, order, sampling=sampling, out_format=out_format), dev_index)
         if args.variant >= 0:
             self.plan.tune(N.TUNE_VARIANT, args.variant)
         if args.no_vector:
@@ -379,6 +391,8 @@ class Workload:
         if args.block_threads:
             self.plan.tune(N.TUNE_BLOCK_THREADS, args.block_threads)
         self.in_px, self.out_px = W * self.stripe_rows, self.plan.out_width * self.plan.out_height
+        # planar output: a frame's buffer is csic_planar_layout.frame_bytes bytes (Y plane + Cb / Cr planes at 256-byte offsets)
+        self.out_words = self.plan.planar_layout.frame_bytes // 4 if self.planar else self.out_px
         self.per_frame_graph = bool(args.per_frame_graph and fps > 1)
         self.lpf = 1 if self.per_frame_graph else fps                     # frames per LAUNCH
         self.launches_per_step = fps if self.per_frame_graph else 1
@@ -394,11 +408,15 @@ class Workload:
         self.sh = C.c_void_p(self.stream.cuda_stream)
         # --pitch-pad: rows padded by that many pixels in HBM (csic_process_pitched_device); the frame and the bytes the
         # kernel moves are the same, only the row addresses change (profiles/r02_probe_pitch.log)
+        # preferred_pitch (the `pitched` side object): the pitches csic_plan_preferred_pitch names, frames batched or not
         self.pad = args.pitch_pad if (args.pitch_pad > 0 and issue == "serial" and fps == 1) else 0
         self.in_pitch = W + self.pad
         self.out_pitch = self.plan.out_width + (self.pad // f if self.pad else 0)
-        n_in = self.stripe_rows * self.in_pitch if self.pad else self.in_px * fps
-        n_out = self.plan.out_height * self.out_pitch if self.pad else self.out_px * fps
+        if preferred_pitch and issue == "serial" and not self.planar:
+            self.in_pitch, self.out_pitch = self.plan.preferred_pitch
+            self.pad = max(self.in_pitch - W, self.out_pitch - self.plan.out_width)       # > 0: the pitched entry point is used
+        n_in = fps * self.stripe_rows * self.in_pitch if self.pad else self.in_px * fps
+        n_out = fps * self.plan.out_height * self.out_pitch if self.pad else self.out_words * fps
         self.ins = [torch.empty(n_in, dtype=torch.int32, device=dev) for _ in range(self.nring)]
         self.outs = [torch.empty(n_out, dtype=torch.int32, device=dev) for _ in range(self.nring)]
         for k, t in enumerate(self.ins):
@@ -443,13 +461,13 @@ class Workload:
             def step(i):
                 self.graphs[i % nring].launch(self.stream)
                 return 0
-        elif fps == 1 and self.pad:
-            self.launch_desc = (f"one launch per step (csic_process_pitched_device, rows padded by {self.pad} px: pitch "
-                                f"{self.in_pitch} / {self.out_pitch} px), eager, one stream")
+        elif self.pad:
+            self.launch_desc = (f"one launch of {fps} frame(s) per step (csic_process_pitched_device, row pitch {self.in_pitch} px in / "
+                                f"{self.out_pitch} px out for {self.W} / {self.plan.out_width} px rows), eager, one stream")
             ip, op = self.in_pitch, self.out_pitch
 
             def step(i):
-                return lib.csic_process_pitched_device(ph, in_ptrs[i % nring], ip, out_ptrs[i % nring], op, 1, sh)
+                return lib.csic_process_pitched_device(ph, in_ptrs[i % nring], ip, out_ptrs[i % nring], op, fps, sh)
         elif fps == 1:
             self.launch_desc = (f"one launch per frame (csic_process_device), {args.batch} per step, eager, one stream" if args.batch > 1 else
                                 "one launch per frame = per step (csic_process_device), eager, one stream")
@@ -669,6 +687,7 @@ def main(argv=None):
     ap.add_argument("--order", default="csq", choices=["csq", "scq"],
                     help="csq = chroma->spatial->quant (north-star order); scq = spatial->chroma->quant (the reference "
                          "app's default order class; with f not dividing W it selects k_generic)")
+    ap.add_argument("--shape", default="", help="EXPERIMENT: W,H -- the config's parameters on another frame size (study configs only)")
     ap.add_argument("--frames-per-step", type=int, default=0,
                     help="override the config's frames per step: N contiguous frames in ONE batched launch "
                          "(csic_process_batch_device) -- puts the tiny cfg2/cfg3 kernels at a size where the roofline means something")
@@ -757,6 +776,7 @@ def main(argv=None):
                     help="N=1: skip the `sustained` leg (the headline launches replayed in bursts for as long as the CPU baseline "
                          "runs on its host thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pitched", action="store_true", help="N=1: skip the `pitched` side object (frames at csic_plan_preferred_pitch, where that is not the packed layout)")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the `verified` object (ring slot 0's output, as the timed launches left it, against the oracle; rank 0, untimed)")
     ap.add_argument("--no-same-mechanism", action="store_true",
@@ -765,6 +785,9 @@ def main(argv=None):
                          "under rocprofv3 (their overlapping launches would distort the per-kernel average the roofline is checked against)")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = top.parse_args(argv)
+    if args.shape:
+        sw, shh = (int(x) for x in args.shape.split(","))
+        CONFIGS[args.config] = (sw, shh) + tuple(CONFIGS[args.config][2:])
     args.batch = args.batch_frames if args.batch_frames > 0 else \
         (DEFAULT_BATCH.get(args.config, 1) if args.frames_per_step <= 0 and not args.per_frame_graph else 1)
     if args.steps <= 0:
@@ -863,8 +886,8 @@ def main(argv=None):
         step_floor_us = 4.0 * W * (-(-H // f) + -(-W // f) * -(-H // f) / W) / parts / (HBM_PEAK_GBS * 1e3)
         issue = "serial" if parts == 1 else ("direct" if step_floor_us < 7.0 else "hip")
 
-    def make(scaling):
-        return lambda how: Workload(args, csic, torch, dev, dev_index, world, rank, scaling, how)
+    def make(scaling, **kw):
+        return lambda how: Workload(args, csic, torch, dev, dev_index, world, rank, scaling, how, **kw)
 
     wl, issue, elapsed, kern_ms_avg, notes = measure_headline(make(headline_mode), issue, args, comm,
                                                               allow_fallback=(args.issue == "auto"), **hooks)
@@ -903,7 +926,8 @@ def main(argv=None):
 
     head = {"stripe_rows": wl.stripe_rows, "global_rows": wl.global_rows, "nring": wl.nring, "kernel": wl.plan.kernel_name,
             "launch": wl.launch_desc, "alg_bytes": wl.alg_bytes, "lpf": wl.lpf, "out_px": wl.out_px, "in_px": wl.in_px,
-            "fps": wl.fps, "launches_per_replay": wl.launches_per_step}
+            "fps": wl.fps, "launches_per_replay": wl.launches_per_step, "planar": wl.planar,
+            "preferred_pitch": (None if wl.planar else tuple(wl.plan.preferred_pitch)), "out_w": wl.plan.out_width}
 
     def host_ordered_object(w, how_txt):
         """Side object of a direct-issue workload; collective (every rank calls it)."""
@@ -968,6 +992,47 @@ def main(argv=None):
                 sustained = {"unavailable": f"{type(exc).__name__}: {exc}"}
         th.join()
         cpu_res = box.get("res")
+    # ---- planar configs: the reconstruct kernel beside the forward one (N = 1; its own roofline) -------------------------------
+    recon = None
+    if wl.planar and world == 1:
+        try:
+            lay = wl.plan.planar_layout
+            lib, sh, nring = wl.lib, wl.sh, wl.nring
+            npk = max(2, min(8, nring))
+            packed = [torch.empty(wl.out_px * wl.fps, dtype=torch.int32, device=dev) for _ in range(npk)]
+            ph = wl.plan._h
+
+            def rstep(i):
+                return lib.csic_reconstruct_device(ph, wl.out_ptrs[i % nring], C.c_void_p(packed[i % npk].data_ptr()), wl.fps, 0, sh)
+            for i in range(8):
+                wl.N.check(rstep(i))
+            torch.cuda.synchronize(dev)
+            nrec = max(50, min(2000, KL))
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            r0.record(stream)
+            for i in range(nrec):
+                rstep(i)
+            r1.record(stream)
+            torch.cuda.synchronize(dev)
+            rms = r0.elapsed_time(r1) / nrec
+            rbytes = (lay.payload_bytes + 4 * wl.out_px) * wl.fps
+            recon = {"kernel": "k_recon (csic_reconstruct_device, planar -> packed ARGB)", "ms_per_launch": round(rms, 5), "launches": nrec,
+                     "algorithmic_bytes_per_launch": rbytes, "achieved_GB/s": round(rbytes / (rms * 1e-3) / 1e9, 1),
+                     "roofline_frac": round(rbytes / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "output_mpixels_per_s": round(wl.out_px * wl.fps / (rms * 1e-3) / 1e6, 1),
+                     "how": "HIP events around the launches on the launch stream; planar frames = the ring the forward launches wrote; "
+                            "bytes = csic_planar_layout.payload_bytes + 4 per output pixel"}
+            # ... and the identity that pins the format: reconstruct(planar(frame 0)) == the packed plan's output for frame 0
+            W_, H_, a_, b_, bits_, f_, _ = CONFIGS[args.config]
+            smp = csic.Sampling.AVG if args.config.endswith("_avg") else csic.Sampling.HOLD_DECIMATE
+            with csic.Plan(csic.make_c_params(W_, wl.stripe_rows, a_, b_, *bits_, f_, CSQ if args.order == "csq" else SCQ, sampling=smp), dev_index) as pk:
+                want = pk.process_device(wl.ins[0][:wl.in_px])
+                wl.N.check(lib.csic_reconstruct_device(ph, wl.out_ptrs[0], C.c_void_p(packed[0].data_ptr()), 1, 0, sh))
+                torch.cuda.synchronize(dev)
+                recon["reconstruct_equals_packed_path"] = bool(torch.equal(packed[0][:wl.out_px], want.reshape(-1)))
+            del packed
+        except Exception as exc:                                   # noqa: BLE001
+            recon = {"unavailable": f"{type(exc).__name__}: {exc}"}
     # ---- the line checks its own output (rank 0, untimed, local: no collective) -----------------------------------------
     verified = None
     if rank == 0 and not args.no_verify:
@@ -978,11 +1043,11 @@ def main(argv=None):
     keep.clear()
     wl.close()
 
-    def side(scaling, how):
+    def side(scaling, how, **kw):
         """The same K steps in another scaling mode / issue mode, same process, same timing method.  Collective: every rank
         calls it, every rank leaves it with the same verdict (the failure flags are all-reduced after each stage)."""
         g = Guard()
-        w2 = g.run(make(scaling), how)
+        w2 = g.run(make(scaling, **kw), how)
         nfail = comm.failed_ranks(g)
         if nfail:
             if w2 is not None:
@@ -997,6 +1062,10 @@ def main(argv=None):
                    "ms_per_launch": round(el2 * 1e3 / KL, 5), "steps": K, "stripe_rows_per_gpu": w2.stripe_rows, "global_rows": w2.global_rows, "launch": w2.launch_desc,
                    "roofline_frac_rank0": round(w2.alg_bytes / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                    "kernel_ms_avg_rank0": round(km2, 5)}
+            if w2.pad:
+                res["in_pitch_px"], res["out_pitch_px"] = w2.in_pitch, w2.out_pitch
+            elif kw.get("preferred_pitch"):
+                res["in_pitch_px"], res["out_pitch_px"], res["packed"] = w2.in_pitch, w2.out_pitch, "csic_plan_preferred_pitch names the packed layout for these rows"
             if busy["report"] is not None:
                 res["busy_streams"] = busy["report"]
             if how == "direct" and (w2.step_graph is not None or w2.per_frame_graph):
@@ -1010,11 +1079,11 @@ def main(argv=None):
     sides = {}
     want_halo = False
 
-    def safe_side(key, scaling, how):
+    def safe_side(key, scaling, how, **kw):
         """A side measurement must never cost the headline line: side() turns every local failure into an all-reduced verdict;
         what is left (a bug in this file) is caught here and recorded."""
         try:
-            sides[key] = side(scaling, how)
+            sides[key] = side(scaling, how, **kw)
         except Exception as exc:                                   # noqa: BLE001 -- by design, see above
             sides[key] = {"unavailable": f"{type(exc).__name__}: {exc}"}
 
@@ -1042,6 +1111,20 @@ def main(argv=None):
     elif args.direct and can_graph and issue != "direct":
         safe_side("direct_dispatch", headline_mode, "direct")
     profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    # `pitched`: the same frames laid out at the row pitches csic_plan_preferred_pitch names (the caller's choice of layout; the
+    # headline stays packed).  Measured where the rule pads (factor-1 plans: 8k_420_f1, 8k_444_f1); where it names the packed
+    # layout (cfg 4, cfg 5: decimating plans) the object says so and nothing is run twice.
+    if world == 1 and args.stripe_of <= 1 and issue == "serial" and not args.pitch_pad and not head["planar"] \
+            and not args.per_frame_graph and not args.busy_streams and args.streams <= 1 and not args.no_pitched and args.frames_per_step <= 0:
+        if head["preferred_pitch"] == (W, head["out_w"]):
+            sides["pitched"] = {"in_pitch_px": W, "out_pitch_px": head["out_w"],
+                                "packed": "csic_plan_preferred_pitch names the packed layout for this plan: with a decimating factor no padded "
+                                          "layout beats packed rows on these kernels (profiles/r04_probe_pitch.jsonl)"}
+        elif not profiled:
+            safe_side("pitched", headline_mode, "serial", preferred_pitch=True)
+            if isinstance(sides.get("pitched"), dict) and "value" in sides["pitched"]:
+                sides["pitched"]["note"] = ("rows at csic_plan_preferred_pitch (1 KiB of padding per row for factor-1 plans); same frames, same "
+                                            "kernel, same timing; never `value`")
     if world == 1 and args.stripe_of <= 1 and args.config == "cfg4" and can_graph and issue == "serial" and args.batch > 1 \
             and not args.pitch_pad and not args.no_same_mechanism and not args.busy_streams:
         # Like for like across N: `value` at N = 2 comes from hipGraph chains and at N = 4 / 8 from direct dispatch (see --issue);
@@ -1107,7 +1190,8 @@ def main(argv=None):
                 "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": head["alg_bytes"],
                 # the stricter and the stream-everything byte models, for comparison only
-                "algorithmic_bytes_strict": 8 * out_px * lpf, "algorithmic_bytes_full": (4 * in_px + 4 * out_px) * lpf,
+                "algorithmic_bytes_strict": None if head["planar"] else 8 * out_px * lpf,
+                "algorithmic_bytes_full": None if head["planar"] else (4 * in_px + 4 * out_px) * lpf,
                 "kernel_ms_avg": round(kern_ms_avg, 5),
                 "kernel_ms_event_pair_median": round(kern_ms_pair_med, 5),
                 "timing": "kernel_ms_avg = (HIP event after step K - HIP event before step 1) / launches on the launch "
@@ -1132,6 +1216,8 @@ def main(argv=None):
             line["sustained"] = sustained
         if cpu_res is not None:
             line["cpu_baseline"] = cpu_res
+        if recon is not None:
+            line["reconstruct"] = recon
         if verified is not None:
             line["verified"] = verified
         print(json.dumps(line), flush=True)

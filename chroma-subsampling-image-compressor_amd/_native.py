@@ -101,6 +101,8 @@ PROTOTYPES = {
     "csic_planar_layout_of": (C.c_int, [C.POINTER(CsicParams), C.POINTER(CsicPlanarLayout)]),
     "csic_reconstruct_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "csic_plan_preferred_pitch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "csic_debug_build": (C.c_int, []),
+    "csic_debug_probe_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "csic_strerror": (C.c_char_p, [C.c_int]),
     "csic_last_error": (C.c_char_p, []),
     "csic_device_count": (C.c_int, []),

@@ -39,6 +39,7 @@ struct KArgs {
     uint32_t my, mcb, mcr;
     int32_t f, hmask, vmask, s_first;   // hmask = h-1, vmask = v-1 (generic kernel; vmask also k_dec SROWS)
     int32_t sc_shift, bc_row_off, bc_col_in;   // k_dec SROWS: log2 f; held-sample decimated row offset / input column
+    int32_t edge_y0;                    // k_avg: first row of edge blocks along grid y (in what used to be padding: the size stays 152)
     int64_t in_frame_px, out_frame_px;  // batch strides (grid z = frame)
     int32_t bdx, bdy, row_step;         // block width/height and gridDim.y * bdy, passed explicitly (see pin_args)
     int32_t ip, op;                     // row pitch of the input / output frame in pixels (>= W / Wo; == when packed)
@@ -75,6 +76,7 @@ const csic_params &plan_params(const csic_plan *pl);
 const Geometry &plan_geometry(const csic_plan *pl);
 int plan_variant(const csic_plan *pl);                       // CSIC_TUNE_VARIANT
 bool plan_nontemporal(const csic_plan *pl);                  // CSIC_TUNE_NONTEMPORAL
+int plan_block_threads(const csic_plan *pl);                 // CSIC_TUNE_BLOCK_THREADS (0 = the library's choice)
 void fill_base_args(const Geometry &g, int32_t ip, int32_t op, KArgs *a);
 // csic_planar.hip: out_format = CSIC_FMT_PLANAR (forward: packed input -> planar frame buffers; name of the kernel a plan takes)
 int planar_forward(const csic_plan *pl, const void *d_in, void *d_planar, int nframes, hipStream_t stream);

@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256) k_dec2v(KArgs a)
 // else -- 1366x768, 1001x1001, but also 1368x768 at f = 4, whose OUTPUT rows are 342 pixels -- fell to the one-pixel-per-lane
 // kernel at a tenth of the speed).  Tiles that lie inside the frame take the register path; the tiles of the last column /
 // last tile row that the frame cuts take orc_process_avg's clamped definition verbatim, output pixel by output pixel
-// (avg_pixel_generic) -- one lane per row and one row of waves per frame.  Clamped loads alone would NOT reproduce the
+// (avg_edge_output) -- one lane per row and one row of waves per frame.  Clamped loads alone would NOT reproduce the
 // definition: a pooling window that hangs over the edge by a whole chroma block would average a block made of the edge pixel
 // only, where the definition re-reads the clamped pixel's own (partly real) block.  Rows and output rows need no alignment:
 // gfx950 executes 16-byte global accesses at any 4-byte address (tools/ubench_unaligned.hip: 6.16-6.35 TB/s against 6.49
@@ -401,38 +401,121 @@ __device__ __forceinline__ void avg_tile(const KArgs &a, const u32x4 (&p)[TH], g
     }
 }
 
-// the output pixels a tile owns, for a tile the frame cuts: by the definition, with the bounds checked
-template <int ROUND, int FMT, int F, int VV, int TH>
-__device__ __forceinline__ void avg_tile_edge(const KArgs &a, gin_t in, gout_t out, int tr, int x4)
+// One output pixel whose pooling window the frame cuts, in registers and bit for bit the clamped definition.
+// The window touches whole chroma blocks only (its origin is a multiple of F, blocks are powers of two): the REGION
+// RW x RH = max(F, h) x max(F, v) pixels, aligned to itself, holds every block any pixel of the window belongs to.  All of it is
+// loaded with clamped coordinates -- RW * RH independent loads in flight, where the run-time loops of avg_pixel_generic wait for
+// each pixel in turn (1001x1001 f = 8: a lane spent 320 dependent loads on its one edge pixel while 63 waited; 21.8 % of the
+// roofline against 82.8 % for 1000x1000).  Then, as the definition has it (orc_process_avg):
+//   * a block whose origin is inside the frame averages its clamped pixels -- exactly what the clamped loads delivered;
+//   * a pixel beyond the frame IS the clamped pixel: it takes that pixel's Y (the load gave it) and that pixel's BLOCK average,
+//     not the average of its own, virtual block -- "hold the last real column, then the last real block row" over the region, a
+//     chain of selects with compile-time indices (no dynamic register indexing).
+template <int ROUND, int FMT, int F, int HH, int VV>
+__device__ __forceinline__ uint32_t avg_edge_output(const KArgs &a, gin_t in, int ro, int co)
 {
-    if (F <= 4) {
-        constexpr int FF = (F <= 4) ? F : 4;
-        constexpr int NOX = 4 / FF, NOY = TH / FF;
-        for (int oi = 0; oi < NOY; ++oi)
-            for (int oj = 0; oj < NOX; ++oj) {
-                const int ro = tr * NOY + oi, co = x4 * NOX + oj;
-                if (ro < a.Ho && co < a.Wo) out1<false>(a, out, (int64_t)ro * a.op + co, avg_pixel_generic<ROUND, FMT, F_ARGB>(a, in, ro, co));
+    constexpr int RW = F > HH ? F : HH, RH = F > VV ? F : VV;
+    constexpr int NLOG = (HH == 4 ? 2 : HH == 2 ? 1 : 0) + (VV == 2 ? 1 : 0);
+    constexpr int FLOG2 = (F == 8 ? 6 : F == 4 ? 4 : F == 2 ? 2 : 0);
+    const int r0w = ro * F, c0w = co * F;
+    const int rr0 = r0w & ~(RH - 1), rc0 = c0w & ~(RW - 1);
+    const int imax = a.H - 1 - rr0, jmax = a.W - 1 - rc0;             // last real row / column in region coordinates (>= 0)
+    const int wi0 = r0w - rr0, wj0 = c0w - rc0;                       // the window inside the region: all of it unless a chroma block
+                                                                      // is larger than the window (h = 4 with F <= 2, v = 2 with F = 1)
+    const u16x2 bhalf = {(HH * VV) >> 1, (HH * VV) >> 1}, zero = {0, 0};
+    uint32_t sy = 0;
+    u16x2 sc = {0, 0};
+    u16x2 prev[RW];                                                   // the chroma of the block row above (the last real one, in the end)
+#pragma unroll
+    for (int j = 0; j < RW; ++j) prev[j] = zero;
+    // one block row (VV pixel rows) at a time -- a rolled loop for the large regions: the whole kernel's occupancy is set by its
+    // largest live range, and a 64-pixel region held in registers at once would cost the tile path two thirds of its waves
+    constexpr int UNROLL = RW * RH <= 16 ? RH : 1;
+#pragma unroll UNROLL
+    for (int bi = 0; bi < RH; bi += VV) {
+        uint32_t Y[VV][RW];
+        u16x2 C[VV][RW];
+#pragma unroll
+        for (int i = 0; i < VV; ++i)
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                const uint32_t px = in1<false>(a, in, (int64_t)min(rr0 + bi + i, a.H - 1) * a.ip + min(rc0 + j, a.W - 1));
+                Y[i][j] = fwd_y(px);
+                C[i][j] = fwd_c_pk<ROUND>(px);
             }
-    } else if ((x4 & 1) == 0) {
-        const int ro = tr, co = x4 >> 1;
-        if (ro < a.Ho && co < a.Wo) out1<false>(a, out, (int64_t)ro * a.op + co, avg_pixel_generic<ROUND, FMT, F_ARGB>(a, in, ro, co));
+        // the block averages of this block row, one value per pixel column
+        u16x2 R[RW];
+#pragma unroll
+        for (int bj = 0; bj < RW; bj += HH) {
+            u16x2 s = {0, 0};
+#pragma unroll
+            for (int i = 0; i < VV; ++i)
+#pragma unroll
+                for (int j = 0; j < HH; ++j) s += C[i][bj + j];
+            if (HH * VV > 1) s = (s + bhalf) >> (unsigned short)NLOG;
+#pragma unroll
+            for (int j = 0; j < HH; ++j) R[bj + j] = s;
+        }
+        // hold the last real column, then the last real (block) row
+#pragma unroll
+        for (int j = 1; j < RW; ++j) R[j] = (j > jmax) ? R[j - 1] : R[j];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) { R[j] = (bi > imax) ? prev[j] : R[j]; prev[j] = R[j]; }
+#pragma unroll
+        for (int i = 0; i < VV; ++i)
+#pragma unroll
+            for (int j = 0; j < RW; ++j) {
+                const bool inwin = (RH == F || (unsigned)(bi + i - wi0) < (unsigned)F) && (RW == F || (unsigned)(j - wj0) < (unsigned)F);
+                sy += inwin ? Y[i][j] : 0u;
+                sc += inwin ? R[j] : zero;
+            }
     }
+    const u16x2 half = {(F * F) >> 1, (F * F) >> 1};
+    const u16x2 qmask = {(unsigned short)a.mcb, (unsigned short)a.mcr};
+    sy = ((sy + ((F * F) >> 1)) >> FLOG2) & a.my;
+    sc = ((sc + half) >> (unsigned short)FLOG2) & qmask;
+    return finish_y<FMT>(sy, chroma_term_q<FMT>(sc.x, sc.y));
 }
 
 // TILES column groups per lane, spaced by the block width: all TILES * TH loads are issued before the first
 // tile's arithmetic starts, so one tile's ~170 VALU ops overlap the other tiles' memory latency.
 // Needs W >= 4 (8 at F = 8) and H >= TH: at least one whole tile for the clamped loads to fall back on (select_rf).
+//
+// Tiles the frame cuts produce nothing here.  The output pixels they would have produced -- the columns co >= Cw and the rows
+// ro >= Rw that whole tiles do not reach -- belong to the EDGE BLOCKS appended to the grid (block rows blockIdx.y >= a.edge_y0;
+// the host sizes them, prepare_common: the grid is a few blocks wide and hundreds tall, so rows of blocks waste none):
+// one output pixel per lane through avg_edge_output, so that a wave of edge work is 64 lanes of edge work.  Two other placements were measured and dropped (profiles/r04_avg_edge_ab.log): evaluating a cut tile's outputs in
+// the lane that owns the tile makes one lane of a wave do two to three tiles' work while 63 wait (1004x1000 f = 8: 73 % against
+// 82 % for 1000x1000; 1020x1020: 64 %), and merely having that branch inside the tile loop cost the f = 2 tile path five
+// points on frames that have no cut tile at all (8192x8192: 77.2 -> 71.9 %; the loop's load / arithmetic overlap did not
+// survive the extra control flow).
 template <int ROUND, int FMT, int F, int HH, int VV, bool NT, int TILES = (F <= 2 ? 2 : 1)>
 __global__ void __launch_bounds__(256) k_avg(KArgs a)
 {
     constexpr int TH = (F > VV) ? F : VV;               // tile rows per lane
     pin_args(a);
     const int W4 = (a.W + 3) >> 2, W4f = a.W >> 2;      // tiles per tile row (the last one possibly cut), whole tiles
-    const int x0 = blockIdx.x * (a.bdx * TILES) + threadIdx.x;
-    if (x0 >= W4) return;
+    const int ntr = (a.H + TH - 1) / TH, ntrf = a.H / TH;
     const gin_t in = frame_in(a);
     const gout_t out = frame_out(a);
-    const int ntr = (a.H + TH - 1) / TH, ntrf = a.H / TH;
+    if ((int)blockIdx.y >= a.edge_y0) {
+        // edge blocks (block-uniform): lanes over the output pixels no whole tile produces -- the right-hand columns first
+        // (all rows), then the bottom rows (the columns left of them)
+        constexpr int NOXY = F <= 4 ? 4 / (F <= 4 ? F : 4) : 1;
+        const int Cw = F == 8 ? (W4f >> 1) : W4f * NOXY;               // output columns / rows whole tiles produce
+        const int Rw = F == 8 ? ntrf : ntrf * (TH / (F <= 4 ? F : 8));
+        const int ecols = a.Wo - Cw, erows = a.Ho - Rw;
+        const int nright = ecols * a.Ho, nbottom = erows * Cw;
+        const int e = (((int)blockIdx.y - a.edge_y0) * (int)gridDim.x + (int)blockIdx.x) * (a.bdx * a.bdy) + (int)(threadIdx.y * a.bdx + threadIdx.x);
+        int ro, co;
+        if (e < nright) { ro = e / ecols; co = Cw + e - ro * ecols; }
+        else if (e - nright < nbottom) { const int e2 = e - nright; const int q = e2 / Cw; ro = Rw + q; co = e2 - q * Cw; }
+        else return;
+        out1<false>(a, out, (int64_t)ro * a.op + co, avg_edge_output<ROUND, FMT, F, HH, VV>(a, in, ro, co));
+        return;
+    }
+    const int x0 = blockIdx.x * (a.bdx * TILES) + threadIdx.x;
+    if (x0 >= W4) return;
     for (int tr = blockIdx.y * a.bdy + threadIdx.y; tr < ntr; tr += a.row_step) {
         u32x4 p[TILES][TH];
         const int trc = min(tr, ntrf - 1);                     // a cut tile loads a whole one (unused) instead of branching
@@ -445,12 +528,9 @@ __global__ void __launch_bounds__(256) k_avg(KArgs a)
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
             const int x4 = x0 + t * a.bdx;
-            if (TILES == 1 || x4 < W4) {
-                // inside the frame?  F = 8: the PAIR of tiles that makes one output (the predicate is the same in both lanes)
-                const bool whole = tr < ntrf && (F == 8 ? (x4 | 1) < W4f : x4 < W4f);
-                if (whole) avg_tile<ROUND, FMT, F, HH, VV, NT, TH>(a, p[t], out, tr, x4);
-                else avg_tile_edge<ROUND, FMT, F, VV, TH>(a, in, out, tr, x4);
-            }
+            // inside the frame?  F = 8: the PAIR of tiles that makes one output (the predicate is the same in both lanes)
+            const bool whole = tr < ntrf && (F == 8 ? (x4 | 1) < W4f : x4 < W4f);
+            if (whole) avg_tile<ROUND, FMT, F, HH, VV, NT, TH>(a, p[t], out, tr, x4);
         }
     }
 }
@@ -606,6 +686,12 @@ __global__ void __launch_bounds__(256) k_checksum(const uint32_t *src, int64_t n
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
+}
+
+// one checked read of the frame described by `a` (csic_debug_probe_device: is the range check of this build live?)
+__global__ void __launch_bounds__(64) k_debug_probe(KArgs a, int64_t off, uint32_t *sink)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *sink = in1<false>(a, (gin_t)(uintptr_t)a.in, off);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1000,14 +1086,29 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
         // the same for k_avg on rows of at most two blocks: 1280-wide f = 4 / 8 (320 lanes) 64 / 61 % -> 80 % with blocks of whole
         // waves that tile the row (profiles/r02_probe_block_avg.log)
         for (int w : {192, 128, 64}) if (lanes_x % w == 0) { bx = w; break; }
+    } else if (fam == FAM_AVG && !forced && lanes_x > tpb && lanes_x % tpb != 0 && lanes_x <= 8 * tpb) {
+        // rows of a few blocks that do not tile (1368-wide f = 4: 342 lanes = [256][86 + 170 idle]): equal blocks instead of a
+        // nearly empty last one
+        const int m = (lanes_x + tpb - 1) / tpb;
+        bx = (lanes_x + m - 1) / m;
     }
     const int by = tpb / bx > 0 ? tpb / bx : 1;
     d->block = dim3(bx, by, 1);
     unsigned gx = (unsigned)((lanes_x + bx - 1) / bx);
+    unsigned gy_edge = 0;
+    if (fam == FAM_AVG) {
+        // k_avg's edge blocks: one lane per output pixel that no whole tile produces (see k_avg), in rows of blocks below the grid
+        const int W4f = g.W / 4, ntrf = g.H / avg_th;
+        const int Cw = g.f == 8 ? W4f / 2 : W4f * (4 / g.f), Rw = g.f == 8 ? ntrf : ntrf * (avg_th / g.f);
+        const int64_t nedge = (int64_t)(g.Wo - Cw) * g.Ho + (int64_t)(g.Ho - Rw) * Cw;
+        const int64_t nblocks = (nedge + (int64_t)bx * by - 1) / ((int64_t)bx * by);
+        gy_edge = (unsigned)((nblocks + gx - 1) / gx);
+    }
     unsigned gy = (unsigned)((rows + by - 1) / by);
-    if (gy > 65535u) gy = 65535u;                     // kernels stride over rows
+    if (gy > 65535u - gy_edge) gy = 65535u - gy_edge;  // kernels stride over rows
     a.bdx = bx; a.bdy = by; a.row_step = (int32_t)gy * by;
-    d->grid = dim3(gx, gy, (unsigned)nframes);
+    a.edge_y0 = (fam == FAM_AVG) ? (int32_t)gy : 0x7FFFFFFF;
+    d->grid = dim3(gx, gy + gy_edge, (unsigned)nframes);
     d->fn = fn;
     return CSIC_OK;
 }
@@ -1095,6 +1196,7 @@ const csic_params &plan_params(const csic_plan *pl) { return pl->p; }
 const Geometry &plan_geometry(const csic_plan *pl) { return pl->g; }
 int plan_variant(const csic_plan *pl) { return pl->variant; }
 bool plan_nontemporal(const csic_plan *pl) { return !pl->no_nt; }
+int plan_block_threads(const csic_plan *pl) { return pl->block_threads; }
 int64_t plan_algorithmic_bytes(const csic_plan *pl)
 {
     int64_t b = 0;
@@ -1207,15 +1309,42 @@ int csic_process_pitched_device(csic_plan *plan, const void *d_in, int32_t in_pi
     return launch(plan, d_in, d_out, nframes, static_cast<hipStream_t>(hip_stream), in_pitch_px, out_pitch_px);
 }
 
+int csic_debug_build(void)
+{
+#if defined(CSIC_DEBUG) && CSIC_DEBUG
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+int csic_debug_probe_device(const void *d_frame, int32_t width, int32_t height, int64_t offset_px, void *d_sink, void *hip_stream)
+{
+    if (!d_frame || !d_sink) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
+    if (width <= 0 || height <= 0) return set_error(CSIC_EINVAL_DIMS, "width and height must be positive");
+    Geometry g{};
+    g.W = width; g.H = height; g.Wo = width; g.Ho = height; g.f = 1; g.h = 1; g.v = 1;
+    KArgs a;
+    fill_base_args(g, width, width, &a);
+    a.in = static_cast<const uint32_t *>(d_frame);
+    HIP_TRY(launch_k(k_debug_probe, dim3(1), dim3(64), static_cast<hipStream_t>(hip_stream), a, offset_px, static_cast<uint32_t *>(d_sink)));
+    clear_error();
+    return CSIC_OK;
+}
+
 int csic_plan_preferred_pitch(const csic_plan *plan, int32_t *in_pitch_px, int32_t *out_pitch_px)
 {
     if (!plan || !in_pitch_px || !out_pitch_px) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
     const Geometry &g = plan->g;
-    // Rows that are a multiple of 8 KiB start in the same DRAM channel: pad them by 1 KiB (256 pixels).  The rule and its
-    // measurements: include/csic.h, tools/probe_pitch2.py, profiles/r04_probe_pitch.jsonl.
-    *in_pitch_px = (g.W % 2048 == 0) ? g.W + 256 : g.W;
-    *out_pitch_px = (g.Wo % 2048 == 0) ? g.Wo + 256 : g.Wo;
-    if (plan->p.out_format == CSIC_FMT_PLANAR) { *in_pitch_px = g.W; *out_pitch_px = g.Wo; }     // planar takes packed rows only
+    // Measured on the round-4 kernels over 2048- to 16384-pixel rows (tools/probe_pitch2.py, profiles/r04_probe_pitch.jsonl):
+    //  * factor 1 (input and output rows equally long, every row read AND written): 1 KiB of padding on both sides is worth
+    //    2-5 points at every width (8192: 76.2 -> 80.3 %, 16384: 76.4 -> 81.5 %, 2048: 75.8 -> 78.7 %, 5120: 76.4 -> 80.5 %);
+    //  * factor 2 / 4 / 8: packed rows are as fast as any padded layout (8192 f = 2: 82.9 % packed, 82.0-82.8 % padded; f = 8:
+    //    79.5 % packed, 74.5-77.7 % padded) -- the gain round 2 measured for k_dec (+2-4 points at 8192) went away with
+    //    k_decflat's flat mapping, and small pads (16-64 pixels) lose up to 10 points.
+    const bool pad = g.f == 1 && plan->p.out_format != CSIC_FMT_PLANAR && g.W >= 1024;
+    *in_pitch_px = pad ? g.W + 256 : g.W;
+    *out_pitch_px = pad ? g.Wo + 256 : g.Wo;
     clear_error();
     return CSIC_OK;
 }

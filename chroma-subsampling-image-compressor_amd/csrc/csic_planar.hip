@@ -185,6 +185,98 @@ __global__ void __launch_bounds__(256) k_planar_flat(KArgs a, PExtra e)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_planar_strided: factor f >= 2 (or any plan with module_width % 4 == 0 that is not the factor-1 image): k_decflat's mapping
+// -- lane = 4 positions of the output stream spaced by the block size, so that every load instruction of a wave reads
+// consecutive OUTPUT positions (input stride f * 4 bytes across lanes, the best the decimator allows) -- and then a 4 x 4
+// transpose inside every quad of lanes, so that each lane ends up with 4 CONSECUTIVE positions and can store its Y (and Cb, Cr)
+// bytes as one dword.  Loading 4 consecutive positions per lane instead (the first version of MODE 1) spread every load
+// instruction over 4 x as many sectors at f = 2: 45 % of the roofline on 8192x8192 against 79 % for the packed k_decflat.
+// The transpose is 4 DPP quad broadcasts + 2 v_perm + 1 v_lshl_or per plane: lane q of a quad collects byte q of its four lanes.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t quad_transpose_bytes(uint32_t w, uint32_t sel_lo, uint32_t sel_hi)
+{
+    const uint32_t a0 = (uint32_t)__builtin_amdgcn_update_dpp((int)w, (int)w, 0x00 /* quad_perm:[0,0,0,0] */, 0xF, 0xF, false);
+    const uint32_t a1 = (uint32_t)__builtin_amdgcn_update_dpp((int)w, (int)w, 0x55 /* quad_perm:[1,1,1,1] */, 0xF, 0xF, false);
+    const uint32_t a2 = (uint32_t)__builtin_amdgcn_update_dpp((int)w, (int)w, 0xAA /* quad_perm:[2,2,2,2] */, 0xF, 0xF, false);
+    const uint32_t a3 = (uint32_t)__builtin_amdgcn_update_dpp((int)w, (int)w, 0xFF /* quad_perm:[3,3,3,3] */, 0xF, 0xF, false);
+    // v_perm_b32(s0, s1, sel): selector bytes 0..3 pick from s1, 4..7 from s0
+    const uint32_t lo = __builtin_amdgcn_perm(a1, a0, sel_lo);          // { a0.byte[q], a1.byte[q], 0, 0 }
+    const uint32_t hi = __builtin_amdgcn_perm(a3, a2, sel_hi);          // { 0, 0, a2.byte[q], a3.byte[q] }
+    return lo | hi;
+}
+
+template <int ROUND, bool NT, bool CHECK>
+__device__ __forceinline__ void planar_strided_body(const KArgs &a, const PExtra &e, gin_t in, gbyte_t fb, uint32_t b0, uint32_t T)
+{
+    const uint32_t n = (uint32_t)e.n;
+    const uint32_t tid = threadIdx.x, q = tid & 3u;
+    uint32_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t j = b0 + (uint32_t)k * T + tid;
+        px[k] = in1<NT>(a, in, stream_in_off(a, CHECK ? min(j, n - 1u) : j));
+    }
+    uint32_t wy = 0, wb = 0, wr = 0;                                       // this lane's 4 positions, byte k = position b0 + k * T + tid
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t cb, cr;
+        fwd_c<ROUND>(px[k], cb, cr);
+        wy |= (fwd_y(px[k]) & a.my) << (8 * k);
+        wb |= (cb & a.mcb) << (8 * k);
+        wr |= (cr & a.mcr) << (8 * k);
+    }
+    // 0x0c = constant zero byte in v_perm_b32's selector
+    const uint32_t sel_lo = 0x0c0c0000u | q | ((4u + q) << 8), sel_hi = 0x00000c0cu | (q << 16) | ((4u + q) << 24);
+    const uint32_t y4 = quad_transpose_bytes(wy, sel_lo, sel_hi);
+    const uint32_t cb4 = quad_transpose_bytes(wb, sel_lo, sel_hi);
+    const uint32_t cr4 = quad_transpose_bytes(wr, sel_lo, sel_hi);
+    // this lane now holds the group of 4 consecutive positions j0 .. j0 + 3 that its quad loaded in round k = q
+    const uint32_t j0 = b0 + q * T + (tid & ~3u);
+    if (CHECK && j0 >= n) return;
+    if (CHECK && j0 + 3u >= n) {                                            // the stream's ragged tail: byte by byte
+        for (uint32_t i = 0; j0 + i < n; ++i) {
+            const uint32_t j = j0 + i;
+            pst1<NT>(e, fb, (int64_t)j, (y4 >> (8 * i)) & 0xFFu);
+            const uint32_t r = (uint32_t)(((uint64_t)j * e.mWm) >> e.kWm), c = j - r * (uint32_t)e.Wm;
+            if ((c & ((1u << e.lhe) - 1u)) == 0 && (r & ((1u << e.lve) - 1u)) == 0) {
+                const int64_t kk = (int64_t)(r >> e.lve) * e.Wc + (c >> e.lhe);
+                pst1<NT>(e, fb, e.cb_off + kk, (cb4 >> (8 * i)) & 0xFFu);
+                pst1<NT>(e, fb, e.cr_off + kk, (cr4 >> (8 * i)) & 0xFFu);
+            }
+        }
+        return;
+    }
+    pst4<NT>(e, fb, (int64_t)j0, y4);
+    // module_width % 4 == 0: the group sits in ONE chroma row at a column that is a multiple of 4
+    const uint32_t r = (uint32_t)(((uint64_t)j0 * e.mWm) >> e.kWm), c0 = j0 - r * (uint32_t)e.Wm;
+    if ((r & ((1u << e.lve) - 1u)) != 0) return;                            // a row without sample points
+    const int64_t k0 = (int64_t)(r >> e.lve) * e.Wc + (c0 >> e.lhe);
+    if (e.lhe == 0) {
+        pst4<NT>(e, fb, e.cb_off + k0, cb4);
+        pst4<NT>(e, fb, e.cr_off + k0, cr4);
+    } else if (e.lhe == 1) {                                                // samples at positions 0 and 2 of the group
+        pst2<NT>(e, fb, e.cb_off + k0, (cb4 & 0xFFu) | ((cb4 >> 8) & 0xFF00u));
+        pst2<NT>(e, fb, e.cr_off + k0, (cr4 & 0xFFu) | ((cr4 >> 8) & 0xFF00u));
+    } else {
+        pst1<NT>(e, fb, e.cb_off + k0, cb4 & 0xFFu);
+        pst1<NT>(e, fb, e.cr_off + k0, cr4 & 0xFFu);
+    }
+}
+
+template <int ROUND, bool NT>
+__global__ void __launch_bounds__(256) k_planar_strided(KArgs a, PExtra e)
+{
+    pin_args(a);
+    const uint32_t T = (uint32_t)e.T;                   // a multiple of 4: quads of lanes are quads of positions
+    const uint32_t b0 = blockIdx.x * (T * 4u);
+    const gin_t in = frame_in(a);
+    const gbyte_t fb = planar_frame(e);
+    // (every lane takes part in the quad exchange: no early exit before it)
+    if ((uint64_t)b0 + (uint64_t)T * 4u <= (uint64_t)e.n) planar_strided_body<ROUND, NT, false>(a, e, in, fb, b0, T);
+    else                                                   planar_strided_body<ROUND, NT, true>(a, e, in, fb, b0, T);
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward, AVG extension
 // ------------------------------------------------------------------------------------------------
 // factor 1, W % 4 == 0, H % VE == 0: a lane owns a 4-pixel x VE-row tile; K tiles per lane spaced by the block width
@@ -274,59 +366,96 @@ __device__ __forceinline__ int64_t recon_index(const PExtra &e, uint32_t r, uint
     return (int64_t)((r - 1u) >> e.lve) * e.Wc + (e.Wc - 1);          // ChromaSubsampler.scala:52-65: the last sample of the row above
 }
 
+// one group of (up to) 4 positions, position by position: the stream's ragged tail, and groups that may straddle chroma rows
+template <int FMT, bool NT>
+__device__ __forceinline__ void recon_slow(const PExtra &e, gcbyte_t fb, gout_t out, uint32_t j0, uint32_t n)
+{
+    uint32_t o[4];
+    const uint32_t cnt = min(4u, n - j0);
+    for (uint32_t q = 0; q < cnt; ++q) {
+        const uint32_t j = j0 + q;
+        const uint32_t r = (uint32_t)(((uint64_t)j * e.mWm) >> e.kWm), c = j - r * (uint32_t)e.Wm;
+        const int64_t k = recon_index(e, r, c);
+        o[q] = finish_y<FMT>(pld1(e, fb, (int64_t)j), chroma_term_q<FMT>(pld1(e, fb, e.cb_off + k), pld1(e, fb, e.cr_off + k)));
+    }
+    if (cnt == 4u) { const u32x4 ov = {o[0], o[1], o[2], o[3]}; st4<NT>(out + j0, ov); }
+    else for (uint32_t q = 0; q < cnt; ++q) out[j0 + q] = o[q];
+}
+
+constexpr int RECON_K = 4;
+
+// K groups per lane spaced by the block size: all their loads (one Y dword and the group's chroma samples each) are in flight
+// before the first inverse transform starts.  The first version took one group per lane -- 8 bytes in flight per lane -- and
+// ran at 58 % of the roofline on a kernel that is three quarters stores.
+template <int FMT, bool FAST, bool NT, bool CHECK>
+__device__ __forceinline__ void recon_body(const PExtra &e, gcbyte_t fb, gout_t out, uint32_t g0, uint32_t T, uint32_t ngroups)
+{
+    const uint32_t n = (uint32_t)e.n;
+    uint32_t y4[RECON_K], cbw[RECON_K], crw[RECON_K];
+    bool live[RECON_K], fast[RECON_K], whole_row[RECON_K];
+#pragma unroll
+    for (int k = 0; k < RECON_K; ++k) {
+        const uint32_t g = g0 + (uint32_t)k * T;
+        live[k] = !CHECK || g < ngroups;
+        const uint32_t j0 = 4u * (CHECK ? min(g, ngroups - 1u) : g);
+        fast[k] = FAST && (!CHECK || j0 + 3u < n);
+        y4[k] = cbw[k] = crw[k] = 0;
+        whole_row[k] = false;
+        if (fast[k]) {
+            // module_width % 4 == 0: the group lies in one chroma row at a column that is a multiple of 4
+            y4[k] = pld4<NT>(e, fb, (int64_t)j0);
+            const uint32_t r = (uint32_t)(((uint64_t)j0 * e.mWm) >> e.kWm), c0 = j0 - r * (uint32_t)e.Wm;
+            if ((r & ((1u << e.lve) - 1u)) != 0 && e.replay_last) {
+                const int64_t kk = recon_index(e, r, c0);                    // one sample for the whole row
+                cbw[k] = pld1(e, fb, e.cb_off + kk);
+                crw[k] = pld1(e, fb, e.cr_off + kk);
+                whole_row[k] = true;
+            } else {
+                const int64_t k0 = (int64_t)(r >> e.lve) * e.Wc + (c0 >> e.lhe);
+                if (e.lhe == 0) { cbw[k] = pld4<false>(e, fb, e.cb_off + k0); crw[k] = pld4<false>(e, fb, e.cr_off + k0); }
+                else if (e.lhe == 1) { cbw[k] = pld2(e, fb, e.cb_off + k0); crw[k] = pld2(e, fb, e.cr_off + k0); }
+                else { cbw[k] = pld1(e, fb, e.cb_off + k0); crw[k] = pld1(e, fb, e.cr_off + k0); }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RECON_K; ++k) {
+        if (!live[k]) continue;
+        const uint32_t j0 = 4u * (g0 + (uint32_t)k * T);
+        if (!fast[k]) { recon_slow<FMT, NT>(e, fb, out, j0, n); continue; }
+        uint32_t cb[4], cr[4];
+        if (whole_row[k] || e.lhe == 2) {
+            cb[0] = cb[1] = cb[2] = cb[3] = cbw[k] & 0xFFu;
+            cr[0] = cr[1] = cr[2] = cr[3] = crw[k] & 0xFFu;
+        } else if (e.lhe == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { cb[q] = (cbw[k] >> (8 * q)) & 0xFFu; cr[q] = (crw[k] >> (8 * q)) & 0xFFu; }
+        } else {
+            cb[0] = cb[1] = cbw[k] & 0xFFu; cb[2] = cb[3] = (cbw[k] >> 8) & 0xFFu;
+            cr[0] = cr[1] = crw[k] & 0xFFu; cr[2] = cr[3] = (crw[k] >> 8) & 0xFFu;
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = finish_y<FMT>((y4[k] >> (8 * q)) & 0xFFu, chroma_term_q<FMT>(cb[q], cr[q]));
+        const u32x4 ov = {o[0], o[1], o[2], o[3]};
+        st4<NT>(out + j0, ov);
+    }
+}
+
 template <int FMT, bool FAST, bool NT>
 __global__ void __launch_bounds__(256) k_recon(KArgs a, PExtra e)
 {
     pin_args(a);
-    const uint32_t n = (uint32_t)e.n;
-    const uint32_t g = blockIdx.x * (uint32_t)e.T + threadIdx.x;
-    const uint32_t j0 = 4u * g;
-    if (j0 >= n) return;
+    (void)a;
+    const uint32_t T = (uint32_t)e.T;
+    const uint32_t ngroups = (uint32_t)((e.n + 3) >> 2);
+    const uint32_t b0 = blockIdx.x * (T * RECON_K);
     const gcbyte_t fb = (gcbyte_t)planar_frame(e);
     const gout_t out = (gout_t)(uintptr_t)e.packed + (int64_t)blockIdx.z * e.n;
-    (void)a;
-    if (j0 + 3u >= n || !FAST) {
-        // the stream's ragged tail, or groups that may straddle chroma rows: position by position
-        uint32_t o[4];
-        const uint32_t cnt = min(4u, n - j0);
-        for (uint32_t q = 0; q < cnt; ++q) {
-            const uint32_t j = j0 + q;
-            const uint32_t r = (uint32_t)(((uint64_t)j * e.mWm) >> e.kWm), c = j - r * (uint32_t)e.Wm;
-            const int64_t k = recon_index(e, r, c);
-            o[q] = finish_y<FMT>(pld1(e, fb, (int64_t)j), chroma_term_q<FMT>(pld1(e, fb, e.cb_off + k), pld1(e, fb, e.cr_off + k)));
-        }
-        if (cnt == 4u) { const u32x4 ov = {o[0], o[1], o[2], o[3]}; st4<NT>(out + j0, ov); }
-        else for (uint32_t q = 0; q < cnt; ++q) out[j0 + q] = o[q];
-        return;
-    }
-    // module_width % 4 == 0: the group lies in one chroma row at a column that is a multiple of 4
-    const uint32_t y4 = pld4<NT>(e, fb, (int64_t)j0);
-    const uint32_t r = (uint32_t)(((uint64_t)j0 * e.mWm) >> e.kWm), c0 = j0 - r * (uint32_t)e.Wm;
-    uint32_t cb[4], cr[4];
-    if ((r & ((1u << e.lve) - 1u)) != 0 && e.replay_last) {
-        const int64_t k = recon_index(e, r, c0);                            // one sample for the whole row
-        cb[0] = cb[1] = cb[2] = cb[3] = pld1(e, fb, e.cb_off + k);
-        cr[0] = cr[1] = cr[2] = cr[3] = pld1(e, fb, e.cr_off + k);
-    } else {
-        const int64_t k0 = (int64_t)(r >> e.lve) * e.Wc + (c0 >> e.lhe);
-        if (e.lhe == 0) {
-            const uint32_t b4 = pld4<false>(e, fb, e.cb_off + k0), r4 = pld4<false>(e, fb, e.cr_off + k0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { cb[q] = (b4 >> (8 * q)) & 0xFFu; cr[q] = (r4 >> (8 * q)) & 0xFFu; }
-        } else if (e.lhe == 1) {
-            const uint32_t b2 = pld2(e, fb, e.cb_off + k0), r2 = pld2(e, fb, e.cr_off + k0);
-            cb[0] = cb[1] = b2 & 0xFFu; cb[2] = cb[3] = b2 >> 8;
-            cr[0] = cr[1] = r2 & 0xFFu; cr[2] = cr[3] = r2 >> 8;
-        } else {
-            cb[0] = cb[1] = cb[2] = cb[3] = pld1(e, fb, e.cb_off + k0);
-            cr[0] = cr[1] = cr[2] = cr[3] = pld1(e, fb, e.cr_off + k0);
-        }
-    }
-    uint32_t o[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = finish_y<FMT>((y4 >> (8 * q)) & 0xFFu, chroma_term_q<FMT>(cb[q], cr[q]));
-    const u32x4 ov = {o[0], o[1], o[2], o[3]};
-    st4<NT>(out + j0, ov);
+    if (b0 + T * RECON_K <= ngroups && (uint64_t)4 * (b0 + T * RECON_K) <= (uint64_t)e.n)
+        recon_body<FMT, FAST, NT, false>(e, fb, out, b0 + threadIdx.x, T, ngroups);
+    else
+        recon_body<FMT, FAST, NT, true>(e, fb, out, b0 + threadIdx.x, T, ngroups);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -354,7 +483,8 @@ static int forward_kind(const csic_plan *pl, const csic_planar_layout &L)
     if (p.sampling == CSIC_SAMPLING_AVG)
         return (!general && g.f == 1 && g.W % 4 == 0 && g.H % g.v == 0) ? 3 : 4;
     if (general || L.module_width % 4 != 0) return 0;
-    return (g.f == 1 && g.W % 4 == 0) ? 2 : 1;
+    if (g.f == 1 && g.W % 4 == 0) return 2;
+    return plan_variant(pl) == 10 ? 5 : 1;
 }
 
 template <int ROUND, bool NT>
@@ -362,7 +492,8 @@ static PlanarFn pick_forward(int kind, int he, int ve)
 {
     switch (kind) {
     case 0: return k_planar_flat<ROUND, 0, NT>;
-    case 1: return k_planar_flat<ROUND, 1, NT>;
+    case 1: return k_planar_strided<ROUND, NT>;
+    case 5: return k_planar_flat<ROUND, 1, NT>;           // the first form of kind 1 (4 consecutive positions per lane): A/B, CSIC_TUNE_VARIANT 10
     case 2: return k_planar_flat<ROUND, 2, NT>;
     case 3:
         if (ve == 1) return he == 1 ? k_planar_avg_f1<ROUND, 1, 1, NT> : he == 2 ? k_planar_avg_f1<ROUND, 2, 1, NT> : k_planar_avg_f1<ROUND, 4, 1, NT>;
@@ -379,7 +510,8 @@ void planar_kernel_name(const csic_plan *pl, char *buf, size_t len)
     const char *nt = plan_nontemporal(pl) ? "nt" : "cached";
     switch (forward_kind(pl, L)) {
     case 0: snprintf(buf, len, "k_planar_flat<%s,general,h%d,v%d,%s>", rn, L.hold_h, L.hold_v, nt); break;
-    case 1: snprintf(buf, len, "k_planar_flat<%s,f%d,h%d,v%d,%s>", rn, plan_geometry(pl).f, L.hold_h, L.hold_v, nt); break;
+    case 1: snprintf(buf, len, "k_planar_strided<%s,f%d,h%d,v%d,%s>", rn, plan_geometry(pl).f, L.hold_h, L.hold_v, nt); break;
+    case 5: snprintf(buf, len, "k_planar_flat<%s,f%d,h%d,v%d,%s>", rn, plan_geometry(pl).f, L.hold_h, L.hold_v, nt); break;
     case 2: snprintf(buf, len, "k_planar_flat<%s,f1x4,h%d,v%d,%s>", rn, L.hold_h, L.hold_v, nt); break;
     case 3: snprintf(buf, len, "k_planar_avg_f1<%s,h%d,v%d,%s>", rn, L.hold_h, L.hold_v, nt); break;
     default: snprintf(buf, len, "k_planar_avg_gen<%s,h%d,v%d>", rn, L.hold_h, L.hold_v); break;
@@ -416,12 +548,24 @@ int planar_forward(const csic_plan *pl, const void *d_in, void *d_planar, int nf
         fill_extra(L, &e);
         e.planar = static_cast<uint8_t *>(d_planar) + (int64_t)f0 * L.frame_bytes;
         dim3 grid, block;
-        if (kind <= 2) {
+        if (kind == 1) {
+            // k_planar_strided: 4 positions per lane, T * 4 positions per block (T = 128 as k_decflat at f = 2 / long rows)
+            const int bt = plan_block_threads(pl);
+            const int T = (bt == 64 || bt == 128 || bt == 256) ? bt : 128;
+            e.T = T;
+            block = dim3((unsigned)T, 1, 1);
+            grid = dim3((unsigned)((e.n + (int64_t)T * 4 - 1) / ((int64_t)T * 4)), 1, (unsigned)nz);
+            a.bdx = T; a.bdy = 1; a.row_step = 1;
+        } else if (kind <= 2 || kind == 5) {
             const int64_t ngroups = (e.n + 3) / 4;
-            e.T = 256;
-            block = dim3(256, 1, 1);
-            grid = dim3((unsigned)((ngroups + 256 * PLANAR_K - 1) / (256 * PLANAR_K)), 1, (unsigned)nz);
-            a.bdx = 256; a.bdy = 1; a.row_step = 1;
+            const int bt = plan_block_threads(pl);
+            // one-wave blocks for the 16-byte-load kernel: a wave's four loads then cover 4 KiB of consecutive pixels
+            // (8192x8192 4:2:0: 71.7 % of the roofline with 256-thread blocks, 77.6 % with 64; profiles/r04_planar_bt.log)
+            const int T = (bt == 64 || bt == 128 || bt == 256) ? bt : (kind == 2 ? 64 : 256);
+            e.T = T;
+            block = dim3((unsigned)T, 1, 1);
+            grid = dim3((unsigned)((ngroups + (int64_t)T * PLANAR_K - 1) / ((int64_t)T * PLANAR_K)), 1, (unsigned)nz);
+            a.bdx = T; a.bdy = 1; a.row_step = 1;
         } else {
             // row-tiled kernels: lanes along x (tiles of 4 pixels for avg_f1 with 2 tiles per lane, output pixels for avg_gen)
             const int lanes_x = kind == 3 ? (g.W / 4 + 1) / 2 : g.Wo;
@@ -477,9 +621,11 @@ extern "C" int csic_reconstruct_device(csic_plan *plan, const void *d_planar, vo
         fill_extra(L, &e);
         e.planar = const_cast<uint8_t *>(static_cast<const uint8_t *>(d_planar)) + (int64_t)f0 * L.frame_bytes;
         e.packed = static_cast<uint32_t *>(d_out) + (int64_t)f0 * e.n;
-        e.T = 256;
-        const int64_t ngroups = (e.n + 3) / 4;
-        const int st = launch_pk(fn, dim3((unsigned)((ngroups + 255) / 256), 1, (unsigned)nz), dim3(256, 1, 1), a, e, stream);
+        const int bt = plan_block_threads(plan);
+        const int T = (bt == 64 || bt == 128 || bt == 256) ? bt : 64;
+        e.T = T;
+        const int64_t ngroups = (e.n + 3) / 4, per_block = (int64_t)T * RECON_K;
+        const int st = launch_pk(fn, dim3((unsigned)((ngroups + per_block - 1) / per_block), 1, (unsigned)nz), dim3((unsigned)T, 1, 1), a, e, stream);
         if (st != CSIC_OK) return st;
     }
     clear_error();

@@ -223,7 +223,8 @@ const char *csic_plan_kernel_name(const csic_plan *plan);
 /* Tuning knobs for A/B measurements; a knob the selected kernel does not have is ignored.
  *   CSIC_TUNE_VARIANT : kernel-family specific variant index (0 = default; 1, 2 = the 16-byte f = 2 kernels, 4 = k_dec for
  *                       f = 1, 5 = k_dec instead of k_decflat on rows that do not tile into whole blocks / waves, 6 = k_decflat wherever it applies, 7 = the one-pixel-per-lane k_generic instead of k_flatgen,
- *                       8 = AVG: the tile kernel only for frames of whole tiles, as in rounds 1-3, 9 = planar: the general kernels instead of the factor-1 fast paths)
+ *                       8 = AVG: the tile kernel only for frames of whole tiles, as in rounds 1-3, 9 = planar: the general kernels instead of the fast paths,
+ *                       10 = planar, factor >= 2: 4 consecutive positions per lane (k_planar_flat) instead of the transposing k_planar_strided)
  *   CSIC_TUNE_FORCE_GENERIC : 1 = always use the one-thread-per-pixel generic kernel
  *   CSIC_TUNE_NONTEMPORAL   : 1 (default) = non-temporal loads/stores for the frame stream, 0 = cached
  *   CSIC_TUNE_NO_VECTOR     : 1 = never use the 16-byte-per-lane kernels
@@ -267,12 +268,28 @@ int  csic_reconstruct_device(csic_plan *plan, const void *d_planar, void *d_out,
                              void *hip_stream);
 
 /* Row pitches, in pixels, at which frames of this plan stream fastest when the CALLER lays them out
- * (csic_process_pitched_device): the width itself unless padding the rows is measured to pay.  Frames whose packed rows are
- * a multiple of 8 KiB -- 2048-, 4096-, 8192-pixel rows -- start every row in the same DRAM channel; 256 pixels (1 KiB) of
- * padding per row spread them (8192x8192: f = 2 78 -> 81-83 %, f = 8 75-77 -> 78-80 % of the HBM roofline; 16- and 64-pixel
- * pads break the rows' 128-byte alignment and lose).  Packed rows remain the default of every entry point and the layout
- * of the headline measurement; this only tells a caller that owns its surfaces what to allocate. */
+ * (csic_process_pitched_device): the width itself unless padding the rows is measured to pay.  Measured on 2048- to
+ * 16384-pixel rows (tools/probe_pitch2.py, profiles/r04_probe_pitch.jsonl): at factor 1 -- input and output rows equally
+ * long, every row read and written -- 256 pixels (1 KiB) of padding on both sides are worth 2-5 points of the HBM roofline
+ * at every width (8192x8192 4:2:0: 76.2 -> 80.3 %); with a decimating factor packed rows are as fast as any padded layout
+ * (the +2-4 points round 2 measured for 8192-pixel rows went away with the flat mapping of k_decflat), and pads of 16-64
+ * pixels lose up to 10 points.  So: width + 256 for factor-1 plans of at least 1024-pixel rows, the width otherwise.
+ * Packed rows remain the default of every entry point and the layout of the headline measurement; this only tells a caller
+ * that owns its surfaces what to allocate. */
 int  csic_plan_preferred_pitch(const csic_plan *plan, int32_t *in_pitch_px, int32_t *out_pitch_px);
+
+/* ---- the range-checking build (diagnostics) ----------------------------------------------------------------------
+ * `make -C chroma-subsampling-image-compressor_amd/csrc debug` builds libcsic_hip_debug.so from the same sources with
+ * -DCSIC_DEBUG: every global access of the pixel kernels is checked against the frame's extent -- (H - 1) * pitch + W
+ * pixels of input, (Ho - 1) * pitch + Wo of output, the planar frame's frame_bytes -- and a violation executes s_trap: the
+ * queue reports a hardware exception and the process aborts instead of reading or writing a neighbour's memory silently.
+ * It is the GPU-side stand-in for a sanitizer (GPU AddressSanitizer is not available on the pool); load it with
+ * CSIC_LIB=<path> (Python host) or link it instead of libcsic_hip.so.  csic_debug_build() tells which build is loaded;
+ * csic_debug_probe_device performs ONE checked read at pixel offset `offset_px` of a width x height frame (into *d_sink):
+ * in the debug build an offset outside the frame traps, in the product build it is the caller's out-of-bounds read --
+ * tests use it (in a child process) to show that the checks are live. */
+int  csic_debug_build(void);
+int  csic_debug_probe_device(const void *d_frame, int32_t width, int32_t height, int64_t offset_px, void *d_sink, void *hip_stream);
 
 /* Convenience synchronous host path: H2D + kernel + D2H through plan-owned staging buffers.
  * in_px must equal width*height and out_px out_width*out_height (planar: frame_bytes / 4). */

@@ -25,6 +25,51 @@ def test_cpu_baseline_object_shape():
     json.dumps(cb)
 
 
+def test_the_line_verifies_itself_and_carries_the_like_for_like_objects():
+    """`verified` (ring slot 0 against the oracle, exit 3 on a mismatch), the N = 1 `hip_streams` /
+    `direct_dispatch` objects the N = 2 / 4 / 8 runs can be divided by, `output_mpixels_per_s`, and a launch label that says
+    what is launched."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'line["verified"] = verified' in src and "sys.exit(3)" in src and "VERIFICATION FAILED" in src
+    assert '"output_mpixels_per_s": round(value * head["out_px"] / max(head["in_px"], 1), 1)' in src
+    assert 'safe_side("hip_streams", headline_mode, "hip")' in src and 'safe_side("direct_dispatch", headline_mode, "direct")' in src
+    assert '"same_mechanism_as"' in src and "one launch per frame (csic_process_device), {args.batch} per step" in src
+    assert "one launch per step (csic_process_device)" not in src
+    assert 'safe_side("pitched", headline_mode, "serial", preferred_pitch=True)' in src
+
+
+def test_verify_against_oracle_on_a_fake_workload(oracle):
+    """The checker's half of `verified` without a GPU: a stand-in workload whose ring slot 0 holds the oracle's output passes,
+    one flipped pixel fails and is counted."""
+    import types
+    import numpy as np
+    bench = _load_bench()
+    bench.CONFIGS["tiny"] = (64, 32, 2, 0, (8, 8, 8), 2, 1)
+    p = oracle.OracleParams(width=64, height=32, chroma_a=2, chroma_b=0, factor=2)
+    want = oracle.process(p, oracle.synth_frame(64 * 32, 0)).reshape(-1)
+
+    class FakeTensor:
+        def __init__(self, a): self.a = a
+        def __getitem__(self, sl): return FakeTensor(self.a[sl])
+        def cpu(self): return self
+        def numpy(self): return self.a.view(np.int32)
+
+    def wl_with(out):
+        return types.SimpleNamespace(args=types.SimpleNamespace(config="tiny"), stripe_rows=32, pad=0, row0=0, planar=False, out_px=out.size,
+                                     outs=[FakeTensor(out.copy())], plan=types.SimpleNamespace(out_width=32, out_height=16))
+    ok = bench.verify_against_oracle(wl_with(want), (3, 1, 2), False, {}, None)
+    assert ok["equal"] is True and ok["frames"] == 1 and ok["pixels"] == want.size and "orc_process_closed_mt" in ok["vs"]
+    keep = {"out": want.copy(), "form": "orc_process_stream"}
+    assert "orc_process_stream" in bench.verify_against_oracle(wl_with(want), (3, 1, 2), False, keep, None)["vs"]
+    bad = want.copy()
+    bad[5] ^= 1
+    res = bench.verify_against_oracle(wl_with(bad), (3, 1, 2), False, {}, None)
+    assert res["equal"] is False and res["mismatching_pixels"] == 1
+    skipped = bench.verify_against_oracle(types.SimpleNamespace(args=types.SimpleNamespace(config="tiny"), stripe_rows=32, pad=256, row0=0), (3, 1, 2), False, {}, None)
+    assert skipped["equal"] is None and "skipped" in skipped
+    json.dumps(ok)
+
+
 def test_config_table_matches_baseline_json():
     bench = _load_bench()
     assert bench.CONFIGS["cfg4"] == (8192, 8192, 2, 0, (8, 8, 8), 2, 1)       # 8192x8192, 4:2:0, sf=2

@@ -41,7 +41,7 @@ def _op(orc, W, H, a, b, bits, f, op, rounding=0, fmt=0):
                             factor=f, op=op, rounding=rounding, out_format=fmt)
 
 
-def _check_one(csic, oracle, W, H, a, b, bits, f, op, rounding, avg, argb, variants=(0, 9)):
+def _check_one(csic, oracle, W, H, a, b, bits, f, op, rounding, avg, argb, variants=(0, 9, 10)):
     import torch
     N = csic._native
     form = "avg" if avg else "stream"
@@ -54,7 +54,7 @@ def _check_one(csic, oracle, W, H, a, b, bits, f, op, rounding, avg, argb, varia
         lay = pl.planar_layout
         for variant in variants:
             pl.tune(N.TUNE_VARIANT, variant)
-            names.add(pl.kernel_name.split("<")[0] + ("*" if variant else ""))
+            names.add(pl.kernel_name.split("<")[0] + ("*" if variant == 9 else ""))
             buf = torch.full((lay.frame_bytes,), 0xEE, dtype=torch.uint8, device="cuda:0")
             pl.process_device(d_in, buf)
             y, cb, cr = pl.split_planar(buf.cpu().numpy())
@@ -89,7 +89,7 @@ def test_planar_random_shapes_vs_oracle(csic, oracle, seed):
         rounding = int(rng.integers(0, 2))
         argb = rng.integers(0, 1 << 32, W * H, dtype=np.uint32)
         seen |= _check_one(csic, oracle, W, H, a, b, bits, f, op, rounding, False, argb)
-    assert "k_planar_flat" in seen and "k_planar_flat*" in seen
+    assert {"k_planar_flat", "k_planar_flat*", "k_planar_strided"} <= seen, seen
 
 
 def test_planar_avg_random_shapes_vs_oracle(csic, oracle):
@@ -217,13 +217,14 @@ def test_planar_is_refused_where_packed_pixels_are_expected(csic, oracle):
 
 
 def test_preferred_pitch_rule(csic):
-    """csic_plan_preferred_pitch: rows that are a multiple of 8 KiB get 1 KiB of padding, everything else stays packed; the
-    padded layout gives the same pixels."""
+    """csic_plan_preferred_pitch: factor-1 plans of long rows get 1 KiB of padding on both sides, everything else stays packed
+    (profiles/r04_probe_pitch.jsonl); the padded layout gives the same pixels."""
     import torch
-    for (W, f, want) in ((8192, 2, (8448, 4352)), (4096, 1, (4352, 4352)), (3840, 4, (3840, 960)), (1000, 2, (1000, 500)), (2048, 8, (2304, 256))):
+    for (W, f, want) in ((8192, 1, (8448, 8448)), (4096, 1, (4352, 4352)), (3840, 1, (4096, 4096)), (8192, 2, (8192, 4096)), (3840, 4, (3840, 960)),
+                         (1000, 1, (1000, 1000)), (2048, 8, (2048, 256))):
         with _plan(csic, W, 16, 2, 0, (8, 8, 8), f, CSQ, fmt=0) as pl:
             assert pl.preferred_pitch == want, (W, f, pl.preferred_pitch)
-    W, H, f = 8192, 24, 2
+    W, H, f = 4096, 24, 1
     with _plan(csic, W, H, 2, 0, (8, 8, 8), f, CSQ, fmt=0) as pl:
         ip, op = pl.preferred_pitch
         d_in = torch.randint(-2**31, 2**31 - 1, (H, W), dtype=torch.int32, device="cuda:0")
