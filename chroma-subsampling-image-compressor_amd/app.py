@@ -83,29 +83,35 @@ class ImageCompressionApp:
         as the baseline the pooled path is byte-compared against (tests/test_gpu_parity.py)."""
         import ctypes as C
         from . import _native as N
-        W, H = ImageProcessorModel.imageSize(inputImagePaths[0])
-        f = spatialFactorToUse
-        top = ImageCompressorTop(W, H, chromaParamA, chromaParamB, yTargetBits, cbTargetBits, crTargetBits,
-                                 f, op1, op2, op3, device=device)
-        finalW, finalH = W // f, H // f
-        for path in outputImagePaths:
-            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)     # outputFile.getParentFile().mkdirs(), ImageProcessorModel.scala:20
-        if decodeThreads == 0:
-            ImageCompressionApp._processImagesSerial(top, inputImagePaths, outputImagePaths, finalW, finalH, depth, compression)
-            top.close()
-            return None
+        inputImagePaths, outputImagePaths = list(inputImagePaths), list(outputImagePaths)
         n = len(inputImagePaths)
+        if n == 0:
+            raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: no input image")
         if n != len(outputImagePaths):
             raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: need as many output as input paths")
-        ins = (C.c_char_p * n)(*[os.fsencode(p) for p in inputImagePaths])
-        outs = (C.c_char_p * n)(*[os.fsencode(p) for p in outputImagePaths])
-        st = N.CsicFilesStats()
+        W, H = ImageProcessorModel.imageSize(inputImagePaths[0])
+        f = spatialFactorToUse
+        finalW, finalH = W // f, H // f
+        if finalW == 0 or finalH == 0:
+            # the reference's collector would build a 0-pixel image (ImageCompressorTopApp.scala:44-45); there is nothing to write,
+            # and a final size of 0 means "the plan's output size" to the C ABI -- refuse instead of writing something else
+            raise N.IllegalArgumentException(N.EINVAL_SIZE, f"requirement failed: a {W}x{H} image at factor {f} leaves no whole output pixel")
+        top = ImageCompressorTop(W, H, chromaParamA, chromaParamB, yTargetBits, cbTargetBits, crTargetBits,
+                                 f, op1, op2, op3, device=device)
         try:
+            for path in outputImagePaths:
+                os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)     # outputFile.getParentFile().mkdirs(), ImageProcessorModel.scala:20
+            if decodeThreads == 0:
+                ImageCompressionApp._processImagesSerial(top, inputImagePaths, outputImagePaths, finalW, finalH, depth, compression)
+                return None
+            ins = (C.c_char_p * n)(*[os.fsencode(p) for p in inputImagePaths])
+            outs = (C.c_char_p * n)(*[os.fsencode(p) for p in outputImagePaths])
+            st = N.CsicFilesStats()
             N.check(N.lib().csic_process_png_files(top.plan()._h, ins, outs, n, decodeThreads or 0, encodeThreads or 0, compression,
                                                    finalW, finalH, C.byref(st)))
+            return {k: getattr(st, k) for k, _ in N.CsicFilesStats._fields_}
         finally:
             top.close()
-        return {k: getattr(st, k) for k, _ in N.CsicFilesStats._fields_}
 
     @staticmethod
     def _processImagesSerial(top, inputImagePaths, outputImagePaths, finalW, finalH, depth, compression):

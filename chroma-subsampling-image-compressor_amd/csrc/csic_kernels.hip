@@ -1089,8 +1089,11 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
     } else if (fam == FAM_AVG && !forced && lanes_x > tpb && lanes_x % tpb != 0 && lanes_x <= 8 * tpb) {
         // rows of a few blocks that do not tile (1368-wide f = 4: 342 lanes = [256][86 + 170 idle]): equal blocks instead of a
         // nearly empty last one
+        // (a multiple of 4 lanes: at f = 8 the two tiles of an output are neighbouring lanes of one quad -- the DPP swap -- so a
+        // block must not start on an odd tile; tools/fuzz_gpu.py found 1032x8 with 129-lane blocks)
         const int m = (lanes_x + tpb - 1) / tpb;
-        bx = (lanes_x + m - 1) / m;
+        bx = ((lanes_x + m - 1) / m + 3) & ~3;
+        if (bx > tpb) bx = tpb;
     }
     const int by = tpb / bx > 0 ? tpb / bx : 1;
     d->block = dim3(bx, by, 1);

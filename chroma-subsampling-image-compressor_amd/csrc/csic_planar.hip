@@ -391,31 +391,28 @@ template <int FMT, bool FAST, bool NT, bool CHECK>
 __device__ __forceinline__ void recon_body(const PExtra &e, gcbyte_t fb, gout_t out, uint32_t g0, uint32_t T, uint32_t ngroups)
 {
     const uint32_t n = (uint32_t)e.n;
-    uint32_t y4[RECON_K], cbw[RECON_K], crw[RECON_K];
-    bool live[RECON_K], fast[RECON_K], whole_row[RECON_K];
+    uint32_t y4[RECON_K], cbw[RECON_K], crw[RECON_K], sh[RECON_K];
+    bool live[RECON_K], fast[RECON_K];
 #pragma unroll
     for (int k = 0; k < RECON_K; ++k) {
         const uint32_t g = g0 + (uint32_t)k * T;
         live[k] = !CHECK || g < ngroups;
         const uint32_t j0 = 4u * (CHECK ? min(g, ngroups - 1u) : g);
         fast[k] = FAST && (!CHECK || j0 + 3u < n);
-        y4[k] = cbw[k] = crw[k] = 0;
-        whole_row[k] = false;
+        y4[k] = cbw[k] = crw[k] = sh[k] = 0;
         if (fast[k]) {
-            // module_width % 4 == 0: the group lies in one chroma row at a column that is a multiple of 4
+            // module_width % 4 == 0: the group lies in one chroma row at a column that is a multiple of 4, so its samples are
+            // 4, 2 or 1 consecutive bytes (h = 1, 2, 4) -- or ONE byte on a row that replays the last sample of the row above.
+            // Branch-free: the aligned dword that holds them is loaded and shifted (planes are padded to 256 bytes), position q
+            // then takes byte q >> sh.  With a branch per case the K groups' loads did not stay in flight together.
             y4[k] = pld4<NT>(e, fb, (int64_t)j0);
             const uint32_t r = (uint32_t)(((uint64_t)j0 * e.mWm) >> e.kWm), c0 = j0 - r * (uint32_t)e.Wm;
-            if ((r & ((1u << e.lve) - 1u)) != 0 && e.replay_last) {
-                const int64_t kk = recon_index(e, r, c0);                    // one sample for the whole row
-                cbw[k] = pld1(e, fb, e.cb_off + kk);
-                crw[k] = pld1(e, fb, e.cr_off + kk);
-                whole_row[k] = true;
-            } else {
-                const int64_t k0 = (int64_t)(r >> e.lve) * e.Wc + (c0 >> e.lhe);
-                if (e.lhe == 0) { cbw[k] = pld4<false>(e, fb, e.cb_off + k0); crw[k] = pld4<false>(e, fb, e.cr_off + k0); }
-                else if (e.lhe == 1) { cbw[k] = pld2(e, fb, e.cb_off + k0); crw[k] = pld2(e, fb, e.cr_off + k0); }
-                else { cbw[k] = pld1(e, fb, e.cb_off + k0); crw[k] = pld1(e, fb, e.cr_off + k0); }
-            }
+            const bool replay = (r & ((1u << e.lve) - 1u)) != 0 && e.replay_last;
+            const int64_t k0 = replay ? (int64_t)((r - 1u) >> e.lve) * e.Wc + (e.Wc - 1) : (int64_t)(r >> e.lve) * e.Wc + (c0 >> e.lhe);
+            sh[k] = replay ? 2u : (uint32_t)e.lhe;
+            const uint32_t bit = 8u * (uint32_t)(k0 & 3);
+            cbw[k] = pld4<false>(e, fb, (e.cb_off + k0) & ~(int64_t)3) >> bit;
+            crw[k] = pld4<false>(e, fb, (e.cr_off + k0) & ~(int64_t)3) >> bit;
         }
     }
 #pragma unroll
@@ -423,20 +420,12 @@ __device__ __forceinline__ void recon_body(const PExtra &e, gcbyte_t fb, gout_t 
         if (!live[k]) continue;
         const uint32_t j0 = 4u * (g0 + (uint32_t)k * T);
         if (!fast[k]) { recon_slow<FMT, NT>(e, fb, out, j0, n); continue; }
-        uint32_t cb[4], cr[4];
-        if (whole_row[k] || e.lhe == 2) {
-            cb[0] = cb[1] = cb[2] = cb[3] = cbw[k] & 0xFFu;
-            cr[0] = cr[1] = cr[2] = cr[3] = crw[k] & 0xFFu;
-        } else if (e.lhe == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { cb[q] = (cbw[k] >> (8 * q)) & 0xFFu; cr[q] = (crw[k] >> (8 * q)) & 0xFFu; }
-        } else {
-            cb[0] = cb[1] = cbw[k] & 0xFFu; cb[2] = cb[3] = (cbw[k] >> 8) & 0xFFu;
-            cr[0] = cr[1] = crw[k] & 0xFFu; cr[2] = cr[3] = (crw[k] >> 8) & 0xFFu;
-        }
         uint32_t o[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = finish_y<FMT>((y4[k] >> (8 * q)) & 0xFFu, chroma_term_q<FMT>(cb[q], cr[q]));
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t b = 8u * ((uint32_t)q >> sh[k]);
+            o[q] = finish_y<FMT>((y4[k] >> (8 * q)) & 0xFFu, chroma_term_q<FMT>((cbw[k] >> b) & 0xFFu, (crw[k] >> b) & 0xFFu));
+        }
         const u32x4 ov = {o[0], o[1], o[2], o[3]};
         st4<NT>(out + j0, ov);
     }
@@ -549,9 +538,9 @@ int planar_forward(const csic_plan *pl, const void *d_in, void *d_planar, int nf
         e.planar = static_cast<uint8_t *>(d_planar) + (int64_t)f0 * L.frame_bytes;
         dim3 grid, block;
         if (kind == 1) {
-            // k_planar_strided: 4 positions per lane, T * 4 positions per block (T = 128 as k_decflat at f = 2 / long rows)
+            // k_planar_strided: 4 positions per lane, T * 4 positions per block
             const int bt = plan_block_threads(pl);
-            const int T = (bt == 64 || bt == 128 || bt == 256) ? bt : 128;
+            const int T = (bt == 64 || bt == 128 || bt == 256) ? bt : 256;
             e.T = T;
             block = dim3((unsigned)T, 1, 1);
             grid = dim3((unsigned)((e.n + (int64_t)T * 4 - 1) / ((int64_t)T * 4)), 1, (unsigned)nz);

@@ -305,3 +305,27 @@ def test_pixel_bundle_types():
     assert p.packed() == 0xFF010203 and csic.PixelBundle.unpack(0x80AABBCC) == (0xAA, 0xBB, 0xCC)
     y = csic.PixelYCbCrBundle(16, 128, 240)
     assert y.packed() == 16 | 128 << 8 | 240 << 16 and csic.PixelYCbCrBundle.unpack(y.packed()) == y
+
+
+def test_process_images_validates_before_it_builds_anything(tmp_path):
+    """list lengths and an empty batch are require()s checked first (no IndexError, no plan left open), and a factor
+    that leaves no whole output pixel is refused instead of being read as 'the plan's output size'."""
+    PS = csic.ProcessingStep
+    args = (4, 4, 8, 8, 8, 2, PS.ChromaSubsampling, PS.SpatialSampling, PS.ColorQuantization)
+    with pytest.raises(csic.IllegalArgumentException, match="no input image"):
+        csic.ImageCompressionApp.processImages([], [], *args)
+    with pytest.raises(csic.IllegalArgumentException, match="as many output as input"):
+        csic.ImageCompressionApp.processImages(["a.png", "b.png"], ["x.png"], *args)
+    one = tmp_path / "one.png"
+    csic.ImageProcessorModel.writeImage(csic.Image(np.full((1, 5), 0xFF112233, dtype=np.uint32)), str(one))
+    with pytest.raises(csic.IllegalArgumentException, match="no whole output pixel"):
+        csic.ImageCompressionApp.processImages([str(one)], [str(tmp_path / "o.png")], *args)
+
+
+def test_host_cpu_budget_defaults_are_reported(tmp_path):
+    """The file pools size themselves by the CPU time the process may use (affinity and cgroup quota): whatever they pick is
+    reported in csic_files_stats -- checked on the GPU; here only that the new ABI symbols of this round are bound."""
+    lib = N.lib()
+    for sym in ("csic_planar_layout_of", "csic_reconstruct_device", "csic_plan_preferred_pitch", "csic_debug_build", "csic_debug_probe_device"):
+        assert hasattr(lib, sym)
+    assert lib.csic_debug_build() == 0

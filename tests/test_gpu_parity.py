@@ -629,6 +629,27 @@ def test_avg_extension_random_shapes(csic, oracle):
             assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H, a, b, f)
 
 
+@pytest.mark.parametrize("W,H", [(1032, 8), (1036, 16), (1366, 24), (1001, 17), (2052, 9), (1922, 10), (4100, 8), (1030, 8), (258 * 4, 24)])
+def test_avg_extension_wide_ragged_rows(csic, oracle, W, H):
+    """Rows wider than one block that do not tile into blocks (the block width is then cut to equal parts: it must stay a
+    multiple of 4 lanes, or the f = 8 lane pairs are torn apart -- found by tools/fuzz_gpu.py on 1032x8), with cut tiles on either
+    edge (the edge blocks), every chroma mode and factor, single frames and a batch."""
+    import torch
+    n = 3
+    host = oracle.synth_frame(n * W * H, W + 7 * H)
+    for (a, b), f in itertools.product([(4, 4), (2, 2), (2, 0), (1, 1), (1, 0)], (1, 2, 4, 8)):
+        wants = [oracle.process(_oparams(oracle, W, H, a, b, (8, 7, 6), f), host[k * W * H:(k + 1) * W * H], form="avg") for k in range(n)]
+        with _avg_plan(csic, W, H, a, b, (8, 7, 6), f) as pl:
+            assert pl.kernel_name.startswith("k_avg<"), pl.kernel_name
+            assert np.array_equal(pl.process_host(host[:W * H]), wants[0]), (pl.kernel_name, W, H, a, b, f)
+            got = pl.process_device(torch.from_numpy(host.view(np.int32)).cuda(), nframes=n).cpu().numpy().view(np.uint32)
+            for k in range(n):
+                assert np.array_equal(got[k], wants[k]), (pl.kernel_name, W, H, a, b, f, k)
+            for bt in (64, 128):
+                pl.tune(csic._native.TUNE_BLOCK_THREADS, bt)
+                assert np.array_equal(pl.process_host(host[:W * H]), wants[0]), (pl.kernel_name, W, H, a, b, f, bt)
+
+
 def test_avg_extension_rejects_other_orders(csic):
     with pytest.raises(csic.IllegalArgumentException):
         csic.ImageCompressorTop(16, 16, 2, 0, 8, 8, 8, 2, 1, 2, 3, sampling=csic.Sampling.AVG)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential run: the HIP path (through the C ABI) against the CPU oracle on fresh seeds.
     python tools/fuzz_gpu.py [seconds] [seed]
-Covers every kernel family, both samplings, both input formats, tuning knobs, odd shapes and batches, and -- for one
+Covers every kernel family, both samplings, both input formats, planar output with its reconstruct kernel (one case in three),
+tuning knobs, odd shapes and batches, and -- for one
 case in three -- the pre-recorded launch paths: the same frames through a frame graph (csic_frame_graph_*), HIP chains or
 direct dispatch, ordered by the host (submit/wait) or with a stream (launch), random branch/queue counts.
 This is a TOOL for hunting corner cases on the GPU box; the fixed-seed versions live in tests/."""
@@ -48,7 +49,7 @@ while time.time() < t_end:
     cp = csic.make_c_params(W, H, a, b, *bits, f, op, rounding=rounding, out_format=fmt,
                             sampling=1 if avg else 0, in_format=1 if ycc_in else 0)
     with csic.Plan(cp, 0) as pl:
-        knobs = [(None, None), (N.TUNE_NONTEMPORAL, 0), (N.TUNE_NO_VECTOR, 1), (N.TUNE_VARIANT, int(rng.integers(1, 5))),
+        knobs = [(None, None), (N.TUNE_NONTEMPORAL, 0), (N.TUNE_NO_VECTOR, 1), (N.TUNE_VARIANT, int(rng.integers(1, 9))),
                  (N.TUNE_FORCE_GENERIC, 1)]
         for knob, val in knobs[: 1 + int(rng.integers(0, len(knobs)))]:
             if knob is not None:
@@ -62,6 +63,27 @@ while time.time() < t_end:
                       f"rounding={rounding} fmt={fmt} avg={avg} ycc_in={ycc_in} knob={knob}={val} first_bad={bad[0].tolist()} "
                       f"count={len(bad)}")
                 sys.exit(1)
+        if rng.random() < 0.3 and not ycc_in:
+            # the same parameters with planar output (CSIC_FMT_PLANAR): the planes against the oracle's planar form of its stream,
+            # and csic_reconstruct_device against the packed oracle output -- default, general (9) and 4-consecutive (10) kernels
+            lay_o, y_o, cb_o, cr_o = orc.planar(op_, frame, avg=avg)
+            cpp = csic.make_c_params(W, H, a, b, *bits, f, op, rounding=rounding, out_format=2, sampling=1 if avg else 0)
+            d_in = torch.from_numpy(frame.view(np.int32)).cuda()
+            with csic.Plan(cpp, 0) as pp:
+                for variant in (0, 9, 10)[: 1 + int(rng.integers(0, 3))]:
+                    pp.tune(N.TUNE_VARIANT, variant)
+                    if rng.random() < 0.3:
+                        pp.tune(N.TUNE_BLOCK_THREADS, int(rng.choice([0, 64, 128, 256])))
+                    buf = pp.process_device(d_in)
+                    y, cb, cr = pp.split_planar(buf.cpu().numpy())
+                    back = pp.reconstruct_device(buf, out_format=fmt).cpu().numpy().view(np.uint32)
+                    fam = pp.kernel_name.split("<")[0] + ("*" if variant == 9 else "")
+                    families[fam] = families.get(fam, 0) + 1
+                    if not (np.array_equal(y, y_o) and np.array_equal(cb, cb_o) and np.array_equal(cr, cr_o) and np.array_equal(back, want)):
+                        print(f"MISMATCH (planar) seed={seed} case={n} {pp.kernel_name} variant={variant} W={W} H={H} a={a} b={b} bits={bits} f={f} op={op} "
+                              f"rounding={rounding} fmt={fmt} avg={avg} y={np.array_equal(y, y_o)} cb={np.array_equal(cb, cb_o)} cr={np.array_equal(cr, cr_o)} "
+                              f"recon={np.array_equal(back, want)}")
+                        sys.exit(1)
         if rng.random() < 0.34 and not ycc_in:
             # the same frame, 1-5 copies with different contents, through a pre-recorded frame graph
             for knob in (N.TUNE_NONTEMPORAL, N.TUNE_NO_VECTOR, N.TUNE_VARIANT, N.TUNE_FORCE_GENERIC):
