@@ -9,21 +9,29 @@
 // the row above" quirk), so  reconstruct(planar(x)) == packed(x)  bit for bit (tests/test_gpu_planar.py, against the oracle).
 //
 // Kernels (wave64; HBM-bound byte work, no LDS, no MFMA):
-//   k_planar_flat<ROUND, MODE, NT>  HOLD_DECIMATE, every order and shape.  Lanes over groups of 4 consecutive positions of
-//                      the OUTPUT stream, K = 4 groups per lane spaced by the block size (every load / store instruction of
-//                      a wave is contiguous in the stream): 4 Y bytes leave as one 4-byte store.
-//                        MODE 2  factor 1, W % 4 == 0: one 16-byte load per group; Cb / Cr of a group leave as one 4-, 2- or
-//                                1-byte store (h = 1, 2, 4); rows without sample points (4:x:0 odd rows) compute Y only.
-//                        MODE 1  module_width % 4 == 0 (a group never straddles chroma rows): 4-byte loads at stride f
-//                                (rows r % f != 0 are never read), the same packed chroma stores.
-//                        MODE 0  anything else (spatial before chroma with ragged widths): per-position chroma byte stores.
+//   k_planar_flat<ROUND, MODE, NT>  HOLD_DECIMATE.  Lanes over groups of 4 consecutive positions of the OUTPUT stream, K = 4
+//                      groups per lane spaced by the block size: 4 Y bytes leave as one 4-byte store.
+//                        MODE 2  factor 1, W % 4 == 0 (the stream IS the image): one 16-byte load per group; Cb / Cr of a group
+//                                leave as one 4-, 2- or 1-byte store (h = 1, 2, 4); rows without sample points (4:x:0 odd rows)
+//                                compute Y only.  One-wave blocks: a wave's four loads cover 4 KiB of consecutive pixels.
+//                        MODE 0  anything whose groups may straddle chroma rows (module_width % 4 != 0: spatial before chroma
+//                                with ragged widths): 4-byte loads, per-position chroma byte stores.
+//                        MODE 1  (CSIC_TUNE_VARIANT 10 only) the first form of k_planar_strided's job, kept for A/B.
+//   k_planar_strided<ROUND, NT>  HOLD_DECIMATE with a factor >= 2 (module_width % 4 == 0): k_decflat's mapping -- 4 positions per
+//                      lane spaced by the block size, loads at stride f (rows r % f != 0 are never read) -- and a 4 x 4 byte
+//                      transpose inside each quad of lanes (DPP + v_perm), after which a lane owns 4 consecutive positions and
+//                      stores Y, Cb, Cr as dwords.
 //   k_planar_avg_f1<ROUND, HE, VE, NT>  AVG extension, factor 1, whole 4 x VE tiles: a lane owns a 4-pixel x VE-row tile
 //                      (VE 16-byte loads), so every h x v chroma block lies in its registers: true 4:2:2 / 4:2:0 / 4:1:1
 //                      box-filtered chroma -- what the north star's prose describes -- at 1.5-3 bytes per pixel out.
 //   k_planar_avg_gen<ROUND>  AVG, anything else: one output position per lane by the definition (avg_pixel_generic).
-//   k_recon<FMT, FAST, NT>  planar -> packed: 4 positions per lane, one 4-byte Y load, the chroma samples of the group as
-//                      one 4- / 2- / 1-byte load when module_width % 4 == 0 (FAST), per-position byte loads otherwise;
-//                      one 16-byte store.
+//   k_recon<FMT, FAST, NT>  planar -> packed: K = 4 groups of 4 positions per lane; per group one 4-byte Y load and the aligned
+//                      dword that holds the group's chroma samples (branch-free: shifted into place), one 16-byte store;
+//                      FAST needs module_width % 4 == 0, otherwise position by position.
+// Measured on 8192x8192 (profiles/r04_bench_all_configs.jsonl, r04_planar_bt.log): 4:2:0 at factor 1 -- 5.5 algorithmic bytes per pixel
+// instead of 8 -- k_planar_flat 77 % of the 8 TB/s roofline (59.8 us per frame against 87.3 us for the packed k_f1x4),
+// k_planar_avg_f1 77 %; factor 2 (3 bytes per output pixel) k_planar_strided 72-74 % (the 4-consecutive form: 45 %);
+// k_recon 67-72 %.
 // Algorithmic bytes: input as for the packed path (4 * W * ceil(H / f), AVG: 4 * W * H) + csic_planar_layout.payload_bytes;
 // reconstruct: payload_bytes + 4 * n.
 #include <cstdio>

@@ -9,7 +9,7 @@
 #   stripes  : bench.py --stripe-of 2/4/8 -> bench_stripe_of.jsonl
 set -o pipefail
 STAGE=${1:-bench}
-TAG=${2:-r03}
+TAG=${2:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -32,14 +32,17 @@ bench)
   $B --config sq1000 --order scq --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config sq1024 --order scq --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1
   $B --config sq1000 --frames-per-step 1024 >> "$J" 2>> "$OUT/bench.err" || exit 1      # the SAME 1000x1000 frames, chroma before spatial: k_decflat
-  $B --config sq1000 --frames-per-step 1024 --variant 5 >> "$J" 2>> "$OUT/bench.err" || exit 1   # ... and k_dec on them (A/B, CSIC_TUNE_VARIANT 5)
-  python bench.py --no-cpu-baseline --variant 5 >> "$J" 2>> "$OUT/bench.err" || exit 1        # the headline frames through k_dec (round 2's kernel; A/B)
-  $BN --config cfg5 --variant 5 >> "$J" 2>> "$OUT/bench.err" || exit 1                           # cfg 5, one batched launch, through k_dec (A/B)
-  $BN --config sq1000 --order scq --frames-per-step 1024 --variant 7 >> "$J" 2>> "$OUT/bench.err" || exit 1   # row 16's frames through k_generic (A/B)
+  # round 4: the planar output format (forward kernels; each line carries its `reconstruct` object) ...
+  for c in planar_8k_420_f1 planar_8k_420_f1_avg planar_cfg4; do $BN --config $c >> "$J" 2>> "$OUT/bench.err" || exit 1; done
+  # ... and the AVG tile kernel on frames it used to refuse, each next to its nearest whole-tile neighbour (256 frames per launch)
+  for c in avg_1366x768_sf4 avg_1368x768_sf4 avg_1001_sf8 avg_1000_sf8 avg_1922x1082_sf2 avg_1920x1080_sf2; do
+    $BN --config $c --frames-per-step 256 >> "$J" 2>> "$OUT/bench.err" || exit 1; done
+  $BN --config avg_1366x768_sf4 --frames-per-step 256 --variant 8 >> "$J" 2>> "$OUT/bench.err" || exit 1   # A/B: rounds 1-3's rule (k_avg_generic for anything but whole tiles)
+  $BN --config avg_1001_sf8 --frames-per-step 256 --variant 8 >> "$J" 2>> "$OUT/bench.err" || exit 1
   wc -l "$J"
   ;;
 profile)
-  for c in cfg4 cfg5 8k_444_f1 8k_420_f1; do
+  for c in cfg4 cfg5 8k_444_f1 8k_420_f1 planar_8k_420_f1 planar_8k_420_f1_avg avg_8k_420_sf2; do
     bash tools/profile.sh $TAG $c > "$OUT/profile_$c.log" 2>&1 || { tail -5 "$OUT/profile_$c.log"; exit 1; }
     echo "profiled $c"
   done
