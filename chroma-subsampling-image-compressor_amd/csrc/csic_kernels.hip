@@ -1108,7 +1108,14 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
         gy_edge = (unsigned)((nblocks + gx - 1) / gx);
     }
     unsigned gy = (unsigned)((rows + by - 1) / by);
-    if (gy > 65535u - gy_edge) gy = 65535u - gy_edge;  // kernels stride over rows
+    if (gy > 65535u - gy_edge - 1u) gy = 65535u - gy_edge - 1u;  // kernels stride over rows
+    if (gy_edge > 0 && nframes > 1 && (gx * (gy + gy_edge)) % 8u == 0) {
+        // XCD-aware: workgroups go to the 8 XCDs round-robin in dispatch order, so with a multiple of 8 blocks per frame the
+        // few (slower, latency-bound) edge blocks of EVERY frame of a batch land on the same XCDs.  1922x1082 at f = 2 -- 541 + 3
+        // block rows -- ran at 66 % where 1922x1080 and 1922x1084 ran at 74 % (profiles/r04_avg_1922_sweep.log).  One more
+        // (empty) block row per frame rotates them.
+        gy_edge += 1;
+    }
     a.bdx = bx; a.bdy = by; a.row_step = (int32_t)gy * by;
     a.edge_y0 = (fam == FAM_AVG) ? (int32_t)gy : 0x7FFFFFFF;
     d->grid = dim3(gx, gy + gy_edge, (unsigned)nframes);
