@@ -99,6 +99,19 @@ template <bool NT> __device__ __forceinline__ void out2(const KArgs &a, gout_t o
 template <bool NT> __device__ __forceinline__ void out4(const KArgs &a, gout_t out, int64_t off, u32x4 v)
 { CSIC_CHECK(off >= 0 && off + 4 <= out_extent(a)); (void)a; st4<NT>(out + off, v); }
 
+// A kernel that picks, block-uniformly, between a straight-line body and a bounds-checked copy of it ends both with the same
+// store; LLVM's SimplifyCFG then sinks that store into a common tail -- and the hardware waits there with s_waitcnt vmcnt(0) for
+// every earlier load AND store of the wave before it may issue the last one.  On the headline kernel that was 1 us per launch
+// (8192x8192 f = 2: 31.8 -> 32.8 us, 79.0 -> 76.8 % of the roofline; found in round 4 by diffing the ISA against round 3's after
+// a refactoring that did not touch the kernel's arithmetic -- the number of such sinks in the object went from 76 to 248).  An
+// empty volatile asm as the LAST statement of the straight-line body makes the two tails differ: nothing is emitted, nothing
+// sinks.  (tools: `make -C csrc asm`, then grep sink.split in build/asm/*.s)
+#ifdef CSIC_NO_TAIL_BARRIER      // (A/B builds only: tools/, never shipped)
+__device__ __forceinline__ void keep_tail_apart() {}
+#else
+__device__ __forceinline__ void keep_tail_apart() { asm volatile("; end of the straight-line body" ::: ); }
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // per-pixel arithmetic
 // ------------------------------------------------------------------------------------------------

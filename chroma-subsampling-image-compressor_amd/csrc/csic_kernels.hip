@@ -157,6 +157,7 @@ __device__ __forceinline__ void dec_rows(const KArgs &a, gin_t in, gout_t out, i
                 const int srow = ((r - 1) << a.sc_shift) + a.bc_row_off; // decimated row of the held sample
                 const uint32_t bpx = in1<false>(a, in, (int64_t)(srow * F) * a.ip + a.bc_col_in);
                 dec_chunk<ROUND, FMT, F, HOLD, true, K, NT, CHECK>(a, in, rowoff, out, orowoff, co0, bx, bpx);
+                keep_tail_apart();                                       // (or its last store is merged with the other chunk's)
                 continue;
             }
         }
@@ -241,6 +242,7 @@ __device__ __forceinline__ void decflat_body(const KArgs &a, gin_t in, gout_t ou
             out1<NT>(a, out, oo[k], finish<FMT>(px[k], a.my, t));
         }
     }
+    if (!CHECK) keep_tail_apart();
 }
 
 template <int ROUND, int FMT, int F, int HOLD, bool SROWS, int K, bool NT>
@@ -639,6 +641,7 @@ __device__ __forceinline__ void flatgen_body(const KArgs &a, gin_t in, gout_t ou
             out1<NT>(a, out, oo[k], finish<FMT>(px[k], a.my, t));
         }
     }
+    if (!CHECK) keep_tail_apart();
 }
 
 template <int ROUND, int FMT, int K, bool NT>

@@ -172,6 +172,7 @@ __device__ __forceinline__ void planar_flat_body(const KArgs &a, const PExtra &e
             }
         }
     }
+    if (!CHECK) keep_tail_apart();
 }
 
 constexpr int PLANAR_K = 4;
@@ -269,6 +270,7 @@ __device__ __forceinline__ void planar_strided_body(const KArgs &a, const PExtra
         pst1<NT>(e, fb, e.cb_off + k0, cb4 & 0xFFu);
         pst1<NT>(e, fb, e.cr_off + k0, cr4 & 0xFFu);
     }
+    if (!CHECK) keep_tail_apart();
 }
 
 template <int ROUND, bool NT>
@@ -437,6 +439,7 @@ __device__ __forceinline__ void recon_body(const PExtra &e, gcbyte_t fb, gout_t 
         const u32x4 ov = {o[0], o[1], o[2], o[3]};
         st4<NT>(out + j0, ov);
     }
+    if (!CHECK) keep_tail_apart();
 }
 
 template <int FMT, bool FAST, bool NT>
