@@ -186,14 +186,14 @@ def test_step_defaults_follow_the_batch():
 
 def test_baseline_md_table_is_the_rendered_artifact():
     """BASELINE.md section 3 must be, line for line, what tools/render_baseline_table.py renders from the committed
-    profiles/r03_bench_all_configs.jsonl -- a number in the document that is not in the artefact is a stale number."""
+    profiles/r04_bench_all_configs.jsonl -- a number in the document that is not in the artefact is a stale number."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "render_baseline_table.py")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     doc = open(os.path.join(ROOT, "BASELINE.md"), encoding="utf-8").read()
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) >= 19
     for l in lines:
-        assert l in doc, "BASELINE.md is out of date with profiles/r03_bench_all_configs.jsonl: " + l[:120]
+        assert l in doc, "BASELINE.md is out of date with profiles/r04_bench_all_configs.jsonl: " + l[:120]
 
 
 def test_committed_traffic_matches_the_checked_out_sources():

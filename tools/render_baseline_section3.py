@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools/render_baseline_section3.py -- rewrites section 3 of BASELINE.md from the committed round-3 artefacts (the table via
+"""tools/render_baseline_section3.py -- rewrites section 3 of BASELINE.md from the committed round-4 artefacts (the table via
 tools/render_baseline_table.py; the kernel-stats, traffic and A/B figures from their files), so that every number in that
-section is a number in a file under profiles/."""
+section is a number in a file under profiles/.  (Round 3's version of this script and of the section: git history.)"""
 import json
 import os
 import subprocess
@@ -23,89 +23,92 @@ def main():
     table = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "render_baseline_table.py")], capture_output=True, text=True, check=True).stdout
     doc = open(os.path.join(ROOT, "BASELINE.md"), encoding="utf-8").read()
     head = doc[:doc.index("## 3. Numbers measured by the build")]
-    rows = [json.loads(l) for l in open(P("r03_bench_all_configs.jsonl"))]
-    kname, kcalls, kavg = stats_row(P("r03_kernel_stats.csv"), "k_decflat")
-    _, ncalls, navg = stats_row(P("r03_kernel_stats_no_sustained.csv"), "k_decflat")
+    rows = [json.loads(l) for l in open(P("r04_bench_all_configs.jsonl"))]
+    pct = lambda i: 100 * rows[i - 1]["roofline"]["frac"]
+    us = lambda i: 1e3 * rows[i - 1]["ms_per_launch"]
+    kname, kcalls, kavg = stats_row(P("r04_kernel_stats.csv"), "k_decflat")
+    _, ncalls, navg = stats_row(P("r04_kernel_stats_no_sustained.csv"), "k_decflat")
     t = json.load(open(P("pmc_traffic.json")))
-    bs = {}
-    for l in open(P("r03_busy_streams.jsonl")):
-        r = json.loads(l)
-        k = (r.get("busy_streams") or {}).get("streams", 0)
-        what = r["config"]["issue"] if r["config"]["launches_per_step"] > 1 else "batched"
-        q = r["config"]["launch"]
-        key = what + (" 3of4" if "3 of 4" in q else "")
-        bs[(key, k)] = 100 * r["roofline"]["frac"]
-    ab = [json.loads(l) for l in open(P("r03_headline_flat_ab.jsonl"))]
-    hd = [r for r in ab if r["config"]["stripe_rows_per_gpu"] == 8192]
-    mean = lambda xs: sum(xs) / len(xs)
-    kd = mean([r["roofline"]["kernel_ms_avg"] for r in hd if "k_dec<" in r["config"]["kernel"]]) * 1e3
-    kf = mean([r["roofline"]["kernel_ms_avg"] for r in hd if "k_decflat<" in r["config"]["kernel"]]) * 1e3
-    a20, a21, a22 = rows[19], rows[20], rows[21]   # the A/B lines at the end of the file
     r = lambda k: t[k]["traffic_over_algorithmic"]
-    sec3 = f"""## 3. Numbers measured by the build (round 3, one MI355X, device-resident frames, FLOOR_HW)
+    drv = json.load(open(P("r04_bench.json")))
+    rep = [json.loads(l)["roofline"]["frac"] for l in open(P("r04_bench_repeat.jsonl"))]
+    st = [json.loads(l) for l in open(P("r04_bench_stripe_of.jsonl"))]
+    hio = json.load(open(P("r04_host_io.json")))["cfg5_from_files"]
+    rc = lambda i: rows[i - 1]["reconstruct"]
+    sec3 = f"""## 3. Numbers measured by the build (round 4, one MI355X, device-resident frames, FLOOR_HW)
 
-Every row below is one line of `profiles/r03_bench_all_configs.jsonl` (`tools/artifacts.sh bench`; this table is rendered
+Every row below is one line of `profiles/r04_bench_all_configs.jsonl` (`tools/artifacts.sh bench`; this table is rendered
 from that file by `tools/render_baseline_table.py`, and this whole section by `tools/render_baseline_section3.py`, so each number
 here is a number in a file under `profiles/`). Kernel time = HIP events on the launch stream, cross-checked with
-`rocprofv3 --kernel-trace --stats` of the default command: `profiles/r03_kernel_stats.csv`, `{kname.replace("void csic::", "").replace("(csic::KArgs)", "")}`
-{kavg / 1e3:.3f} µs average over {kcalls:,} launches — that run includes the `sustained` leg (≈ 240 000 launches in bursts while the
+`rocprofv3 --kernel-trace --stats` of the default command: `profiles/r04_kernel_stats.csv`, `{kname.replace("void csic::", "").replace("(csic::KArgs)", "")}`
+{kavg / 1e3:.3f} µs average over {kcalls:,} launches — that run includes the `sustained` leg (≈ 230 000 launches in bursts while the
 CPU baseline runs, at operating temperature); a second trace of the same command with `--no-sustained` isolates the prewarm,
-warm-up and timed launches: `profiles/r03_kernel_stats_no_sustained.csv`, {navg / 1e3:.3f} µs over {ncalls:,} launches. Roofline
+warm-up and timed launches: `profiles/r04_kernel_stats_no_sustained.csv`, {navg / 1e3:.3f} µs over {ncalls:,} launches. Roofline
 denominator 8.0 TB/s (spec). Steady-state clocks (400 ms untimed conditioning, `config.prewarm_ms`); default ring sizes (16 GiB of
 distinct input frames per GPU). A step of the headline config (row 1) is a batch of 64 frames, one launch each (DESIGN.md §6);
-every other row is one launch per step (or 64 per-frame launches, rows 9–13). The last column is the same launches through the
-direct-dispatch engine (`--direct`; DESIGN.md §4.1). Round 1's and round 2's tables are in the git history; their artefacts stay
-under `profiles/r01_*`, `profiles/r02_*`.
+every other row is one launch per step (or 64 per-frame launches, rows 9–13). Every line carries `verified` (ring slot 0, as the
+timed launches left it, against the oracle) and exits non-zero on a mismatch. Rounds 1–3's tables are in the git history; their
+artefacts stay under `profiles/r01_*` … `profiles/r03_*`.
+
+The driver's own command on the final sources (`profiles/r04_bench.json`): {drv['value'] / 1e6:.3f} Tpixel/s, {100 * drv['roofline']['frac']:.1f} % of the roofline,
+`roofline.traffic` {drv['roofline']['traffic']:,} B per launch (PMC, {r('cfg4'):.4f} × algorithmic), `sustained` {100 * drv['sustained']['roofline_frac']:.1f} %, and — new at N = 1 — the full
+frame through the two launch mechanisms the N > 1 runs use, so that an efficiency can be formed like for like: `hip_streams`
+{100 * drv['hip_streams']['roofline_frac_rank0']:.1f} % (hipGraph chains: `value` at N = 2), `direct_dispatch` {100 * drv['direct_dispatch']['roofline_frac_rank0']:.1f} % (`value` at N = 4, 8). Four repeats of the
+command on another box: {100 * min(rep):.2f}–{100 * max(rep):.2f} % (`profiles/r04_bench_repeat.jsonl`).
 
 {table}
-The headline kernel changed in round 3: chroma before spatial with h ≤ f now runs `k_decflat` (lanes over the flat decimated
-stream, DESIGN.md §4) except on shapes that take `k_dec`'s one-wave blocks, and what no fast path covers runs `k_flatgen` instead of
-`k_generic` (row 16 against row 22, `CSIC_TUNE_VARIANT` 7: {100 * rows[15]['roofline']['frac']:.1f} % against {100 * a22['roofline']['frac']:.1f} %; 1366×768 at sf 2 / 4: 43 / 45 → 70 / 75 %,
-`profiles/r03_probe_flatgen.log`). Rows 20–21 are A/B lines too, the same frames through
-round 2's `k_dec` (`CSIC_TUNE_VARIANT` 5): headline {100 * a20['roofline']['frac']:.1f} % against row 1's {100 * rows[0]['roofline']['frac']:.1f} %, cfg 5
-{100 * a21['roofline']['frac']:.1f} % against row 2's {100 * rows[1]['roofline']['frac']:.1f} %; four interleaved repeats of the headline:
-{kd:.2f} µs (`k_dec`) against {kf:.2f} µs (`k_decflat`) per launch (`profiles/r03_headline_flat_ab.jsonl`).
-Rows 7–8 are BASELINE configs[1] and [2] exactly as specified — one 64 KiB / 1 MiB frame per launch, launch-bound — and rows
-14–15 the same kernels at 4096 / 1024 frames per launch, where the roofline fraction is about the kernel. Rows 9–13 are
-configs[4] with its 64 4K frames in 64 SEPARATE buffers per step: as literally specified ("hipGraph-captured per-frame launch")
-in one hipGraph chain (round 1: 31 %) and in the HIP backend's default 4 chains; through the direct backend — the same 64
-per-frame launches as AQL packets without barrier bits on the library's own queues — ordered with the launch stream on the device
-by polling kernels (row 11: 3 queues; row 12: created with 4 queues, which a stream-ordered launch now deals over 3 — round 2's
-31 % cliff is gone; the last column gives the same graphs ordered by the host, where all 4 queues are used); and through the
-fused backend, which is no longer 64 launches but one launch over a pointer table (row 13) and is what `csic_frame_graph_create`
-gives by default since round 3 (`CSIC_FRAME_GRAPH_AUTO`); row 2 is the same workload as one batched launch over contiguous
-frames. How the backends hold up beside other busy HIP streams of the host process: `profiles/r03_busy_streams.md` (with two
-streams copying 64 MiB blocks back to back the fused launch keeps {bs[('fused', 2)]:.1f} % — its share of the bandwidth — while
-stream-ordered direct dispatch falls to {bs[('direct', 2)]:.1f} % and hipGraph chains to {bs[('hip', 2)]:.1f} %: the per-frame-launch
-backends are for hosts whose other streams are quiet while frames go through). Rows 16–19 are the 1000×1000 frames whose rows
-are not a whole number of 128-byte lines: `k_flatgen` (spatial before chroma where `h ∤ Wo`, row 16; `k_generic` on the same frames: row 22)
-against `k_dec` on the nearest aligned shape (row 17), and the same frames with chroma before spatial through `k_decflat` (row 18) and through `k_dec` (row 19,
-`CSIC_TUNE_VARIANT` 5: every block on its bounds-checked path). 2/4/8-GPU numbers are filled by the driver's scaling run
-(`SCALE_rNN.json`): at N > 1 `value` is the strong split of ONE 8192×8192 frame (pre-recorded launches on the launch stream:
-hipGraph chains at N = 2, direct dispatch at N = 4 and 8; a mode that fails on any rank is replaced on every rank,
-direct → hip → serial), with the other backend, the host-ordered and the weak-scaling numbers and the `halo_exchange` object
-beside it in the same line; the prediction from one-GPU stripe timings is in DESIGN.md §7 (`profiles/r03_bench_stripe_of.jsonl`),
-the two-, four- and five-rank rehearsals on one GPU in `profiles/r03_multi_rehearsal*.log`, the RCCL communicator at world size 1
-in `profiles/r03_rccl_ws1.log`.
+Rows 1–18 are round 3's rows on round 4's sources. In between, the headline had LOST two points without any change to its
+arithmetic: a refactoring (checked accessors for the range-checking build) changed the IR just enough for SimplifyCFG to sink the
+last store of the kernel's straight-line body and of its bounds-checked twin into one tail behind `s_waitcnt vmcnt(0)`; found
+by diffing the ISA against round 3's, fixed by an empty `asm volatile` at the end of the straight-line body
+(`csic_kernel_ops.h: keep_tail_apart`), A/B on one box: `profiles/r04_tail_sink_ab.log` (76.8 % without, 78.9 % with).
 
-Launch-size study (what an 8192×1024 stripe or one 4K frame costs per launch, and what hides that cost):
-`profiles/r03_small_launch.md`. Video-size sweep (1080p/4K/8K/8192²/1000² × 4 chroma modes × 4 factors × both order classes,
-each step ≥ 768 MB of algorithmic bytes): `profiles/r03_sweep.md`; `k_dec` against `k_decflat` over 22 shapes:
-`profiles/r03_probe_flat.log`. Host side lines (PCIe, host entry points, PNG codec, cfg 5 end to end from files):
-`profiles/r03_host_io.json`.
+New in round 4 (DESIGN.md §0):
+* rows 19–21 — **planar, genuinely subsampled output** (`out_format = CSIC_FMT_PLANAR`: a Y plane + Cb / Cr planes at the chroma
+  sample points; 4:2:0 at factor 1 is 1.5 bytes per pixel out instead of 4, 5.5 algorithmic bytes per pixel instead of 8).
+  8192×8192 4:2:0 sf 1: {us(19):.1f} µs per frame = {pct(19):.1f} % (row 19; the packed `k_f1x4` on the same frames: {us(4):.1f} µs, row 4); the same
+  with box-filtered chroma (AVG extension — what the reference's README and the north star describe): {pct(20):.1f} % (row 20); cfg 4's
+  parameters, 3 bytes per output pixel: {pct(21):.1f} % (row 21; its first form, 4 consecutive positions per lane: 45 %,
+  `profiles/r04_planar_bt.log`). `csic_reconstruct_device` (planar → packed ARGB) beside each: {100 * rc(19)['roofline_frac']:.1f} / {100 * rc(20)['roofline_frac']:.1f} / {100 * rc(21)['roofline_frac']:.1f} %,
+  and `reconstruct(planar(x)) == packed(x)` checked in the line. PMC traffic: {r('planar_8k_420_f1'):.4f} × / {r('planar_8k_420_f1_avg'):.4f} × algorithmic.
+* rows 22–29 — **the AVG tile kernel on every frame shape**: 256 frames per launch, each ragged shape next to its nearest
+  whole-tile neighbour — 1366×768 sf 4 {pct(22):.1f} % against {pct(23):.1f} %, 1001×1001 sf 8 {pct(24):.1f} % against {pct(25):.1f} %, 1922×1082 sf 2 {pct(26):.1f} % against
+  {pct(27):.1f} % — and rows 28–29 the same ragged frames under rounds 1–3's rule (`CSIC_TUNE_VARIANT` 8: `k_avg_generic`): {pct(28):.1f} % and
+  {pct(29):.1f} %. (Rounds 1–3 also sent 1368×768 and 1000×1000 there — output rows of 342 / 125 pixels broke a 16-byte-store
+  rule — so the "aligned" neighbours are themselves 9–13 × faster than they were: `profiles/r04_avg_edge_ab.log`, which also
+  records the four placements of the edge work that were measured.) Headline AVG shape (row 5): {pct(5):.1f} % with packed 16-bit
+  chroma sums (round 3: 74.5 %); traffic {r('avg_8k_420_sf2'):.4f} ×.
+* rows 3–4 carry `pitched`: the same frames with rows at `csic_plan_preferred_pitch` (1 KiB of padding for factor-1 plans):
+  {100 * rows[2]['pitched']['roofline_frac_rank0']:.1f} % and {100 * rows[3]['pitched']['roofline_frac_rank0']:.1f} % against {pct(3):.1f} % and {pct(4):.1f} % packed; for decimating plans the rule names the packed layout (cfg 4, cfg 5: the
+  object says so) — `profiles/r04_probe_pitch.jsonl` (24 width × factor combinations × 13 pad pairs).
+
+Rows 7–8 are BASELINE configs[1] and [2] exactly as specified — one 64 KiB / 1 MiB frame per launch, launch-bound — and rows
+14–15 the same kernels at 4096 / 1024 frames per launch, where the roofline fraction is about the kernel: batch small frames
+(`csic_process_batch_device`). Rows 9–13 are configs[4] with its 64 4K frames in 64 SEPARATE buffers per step: as literally
+specified ("hipGraph-captured per-frame launch") in one hipGraph chain ({pct(9):.1f} %) and in the HIP backend's default 4 chains
+({pct(10):.1f} %) — **a hipGraph of per-frame launches is a 40 % path on this part**: a 4K frame at sf 4 is 1.3 µs of HBM time behind a
+≈ 1.7 µs dependent-kernel boundary; through the direct backend (AQL packets without barrier bits on the library's queues) ordered
+with the launch stream on the device ({pct(11):.1f} % on 3 queues, {pct(12):.1f} % created with 4) or by the host (last column); and through the fused
+backend — one launch over a pointer table, what `csic_frame_graph_create` gives by default — {pct(13):.1f} % (row 2, the same workload
+as one contiguous batch: {pct(2):.1f} %). Rows 16–18 are the 1000×1000 frames whose rows are not a whole number of 128-byte lines.
+
+Strong scaling, one rank's share measured alone (`profiles/r04_bench_stripe_of.jsonl`, the driver's flags): N = 1 {1e3 * st[0]['ms_per_launch']:.2f} µs per
+frame; the 8192×4096 / ×2048 / ×1024 stripes of N = 2 / 4 / 8: {1e3 * st[1]['ms_per_launch']:.2f} / {1e3 * st[2]['ms_per_launch']:.2f} / {1e3 * st[3]['ms_per_launch']:.2f} µs ({100 * st[1]['roofline']['frac']:.1f} / {100 * st[2]['roofline']['frac']:.1f} / {100 * st[3]['roofline']['frac']:.1f} %), i.e.
+{100 * st[0]['ms_per_launch'] / (2 * st[1]['ms_per_launch']):.0f} / {100 * st[0]['ms_per_launch'] / (4 * st[2]['ms_per_launch']):.0f} / {100 * st[0]['ms_per_launch'] / (8 * st[3]['ms_per_launch']):.0f} % of linear before the closing barrier. 2/4/8-GPU numbers themselves are filled by the driver's scaling run
+(`SCALE_rNN.json`); rehearsals with 2 and 4 ranks on one GPU (gloo) and a real RCCL communicator at world size 1:
+`profiles/r04_multi_rehearsal*.log`, `profiles/r04_rccl_ws1.log`.
 
 HBM traffic from PMC counters (FETCH_SIZE ×2, WRITE_SIZE ×1, separate passes, calibrated on known-size launches;
-`profiles/pmc_traffic.json`, each entry keyed on a sha256 of the kernel sources, `traffic_over_algorithmic` = the ratio):
-cfg 4 {t['cfg4']['hbm_bytes_per_launch']:,} B per launch = {r('cfg4')} × the algorithmic 201 326 592 B; cfg 5 {r('cfg5')} × (round 2's `k_dec`: 1.009 ×);
-8192² 4:4:4 sf 1 {r('8k_444_f1')} ×; 8192² 4:2:0 sf 1 {r('8k_420_f1')} ×. The unaligned rows (1024 frames of 1000×1000 per launch, sf 8):
-`k_dec` chroma→spatial {r('sq1000_csq_kdec')} × (reads {t['sq1000_csq_kdec']['hbm_read_bytes_per_launch'] / 512e6:.3f} ×, writes {t['sq1000_csq_kdec']['hbm_write_bytes_per_launch'] / 64e6:.3f} × — row ends split its stores into partial lines),
-`k_decflat` on the same frames {r('sq1000_csq')} × (writes {t['sq1000_csq']['hbm_write_bytes_per_launch'] / 64e6:.3f} ×: what 62 500-byte output frames cost in 32-byte sectors), spatial→chroma
-`k_flatgen` {r('sq1000_scq')} × and `k_generic` {r('sq1000_scq_kgeneric')} ×, against {r('sq1024_csq')} × / {r('sq1024_scq')} × for 1024×1024. Wasted traffic explains 3–5 points of the gap to the aligned shape
-at most; the rest was control flow (fixed by `k_decflat`) and is request efficiency (DESIGN.md §4).
-CPU C (Scala/JVM path): no JVM on the GPU box (`java` not found) — not measured, not substituted; the model to time is written
-(`chroma-subsampling-image-compressor_amd/jvm/scala/jpeg/SoftwareModel.scala`).
+`profiles/pmc_traffic.json`, each entry keyed on a sha256 of the kernel sources): cfg 4 {t['cfg4']['hbm_bytes_per_launch']:,} B per launch = {r('cfg4'):.4f} × the
+algorithmic 201 326 592 B; cfg 5 {r('cfg5'):.4f} ×; 8192² 4:4:4 sf 1 {r('8k_444_f1'):.4f} ×; 8192² 4:2:0 sf 1 {r('8k_420_f1'):.4f} ×; the planar and AVG kernels above.
+Host side (`profiles/r04_host_io.json`): cfg 5 end to end from files, 64 4K PNGs in and 64 out, {hio['best']['wall_s']} s = {hio['best']['Mpixels_per_s']:,.0f} Mpixel/s with
+the pools' new default sizes ({hio['best']['decode_threads']} decoders + {hio['best']['encode_threads']} encoders: twice the CPU budget the cgroup grants, split 2 : 1).
+CPU C (Scala/JVM path): no JVM on the GPU box (`java` not found) — not measured, not substituted; since round 4 the model is
+also ONE Java file that any JDK ≥ 11 runs without a compiler step (`jvm/java/SoftwareModelBench.java`), and `bench.py` times it
+and checks its output frame against the oracle's by checksum wherever `java` exists (`cpu_baseline.jvm`).
 """
     open(os.path.join(ROOT, "BASELINE.md"), "w", encoding="utf-8").write(head + sec3)
+    print("BASELINE.md section 3 rewritten")
 
 
 if __name__ == "__main__":
