@@ -56,6 +56,8 @@ CONFIGS = {
     "cfg5": (3840, 2160, 2, 0, (3, 3, 2), 4, 64),
     "8k_444_f1": (8192, 8192, 4, 4, (8, 8, 8), 1, 1),
     "8k_420_f1": (8192, 8192, 2, 0, (3, 3, 2), 1, 1),
+    "8k_422_f1": (8192, 8192, 2, 2, (8, 8, 8), 1, 1),
+    "8k_410_f1": (8192, 8192, 1, 0, (8, 8, 8), 1, 1),
     # with --order scq: spatial before chroma where f does not divide W -> k_generic; sq1024 is the nearest fast-path shape
     "sq1000": (1000, 1000, 2, 0, (8, 8, 8), 8, 1),
     "sq1024": (1024, 1024, 2, 0, (8, 8, 8), 8, 1),

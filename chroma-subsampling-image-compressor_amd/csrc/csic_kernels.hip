@@ -20,8 +20,10 @@
 //              "replay one pixel for the whole row" cases a per-row broadcast.  Serves f = 2/4/8 in both
 //              order classes (spatial-before-chroma when f | W and h | Wo) and f = 1 for 4:x:0, any width
 //              and pointers that are only 4-byte aligned.
-//   k_f1x4   : factor 1, width % 4 == 0, v = 1.  One lane = 4 consecutive pixels = one 16-byte nt load and
-//              one 16-byte nt store; held chroma is reused inside the lane (h in {2,4} divides 4).
+//   k_f1flat : factor 1, width % 4 == 0 (round 4).  Lanes over groups of 4 consecutive pixels of the flat frame, 4 groups per lane
+//              spaced by the one-wave block: four 16-byte nt loads in flight per lane, a wave covers 4 KiB of consecutive pixels;
+//              held chroma is reused inside the group (h in {2,4} divides 4), 4:x:0 odd rows fetch one row-uniform pixel.
+//   k_f1x4   : its predecessor (one group per lane, 2-D blocks over rows); CSIC_TUNE_VARIANT 11, A/B only.
 //   k_dec2v  : factor 2 variants with 16-byte loads (tuning knob, not the default).
 //   k_generic: one lane = one output pixel, run-time parameters, SURVEY.md App. A.3/A.4 verbatim: the
 //              remaining spatial-before-chroma shapes (chroma counters run on the decimated stream
@@ -81,6 +83,80 @@ __global__ void __launch_bounds__(256) k_f1x4(KArgs a)
         const u32x4 ov = {o[0], o[1], o[2], o[3]};
         out4<NT>(a, out, obase, ov);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_f1flat: factor 1, W % 4 == 0 -- k_f1x4's arithmetic on k_planar_flat's mapping (round 4): lanes over groups of 4 consecutive
+// pixels of the flat frame, K = 4 groups per lane spaced by the one-wave block, so a wave's four 16-byte loads (and stores)
+// cover 4 KiB of consecutive pixels and four loads per lane are in flight.  Group -> (row, column) by an exact multiply-shift.
+// ------------------------------------------------------------------------------------------------
+template <int ROUND, int FMT, int HH, int VV, bool NT, bool CHECK>
+__device__ __forceinline__ void f1flat_body(const KArgs &a, gin_t in, gout_t out, uint32_t g0, uint32_t T, uint32_t ngroups)
+{
+    constexpr int K = 4;
+    u32x4 p[K];
+    uint32_t cpx[K], row[K];
+    int64_t off[K], oo[K];
+    bool odd[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t g = CHECK ? min(g0 + (uint32_t)k * T, ngroups - 1u) : g0 + (uint32_t)k * T;
+        const uint32_t j0 = 4u * g;
+        row[k] = (uint32_t)(((uint64_t)j0 * a.mW) >> a.kW);
+        const uint32_t col = j0 - row[k] * (uint32_t)a.W;
+        off[k] = (int64_t)row[k] * a.ip + col;
+        oo[k] = (int64_t)row[k] * a.op + col;
+        odd[k] = (VV == 2) && (row[k] & 1u);
+    }
+    // 4:x:0 odd rows replay the last sample of the row above: one row-uniform pixel.  Issued AHEAD of the 16-byte stream loads (as
+    // in k_f1x4), only by waves that sit on such a row, and once per row a lane visits -- its K groups are T * 4 pixels apart,
+    // usually inside one row.
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        cpx[k] = 0;
+        if (VV == 2) {
+            const bool fresh = (k == 0) || row[k] != row[k > 0 ? k - 1 : 0];
+            if (__builtin_amdgcn_ballot_w64(odd[k] && fresh) != 0)
+                cpx[k] = in1<false>(a, in, odd[k] ? (int64_t)(row[k] - 1u) * a.ip + a.last_sample_col : off[k]);
+            if (k > 0 && !fresh) cpx[k] = cpx[k - 1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) p[k] = in4<NT>(a, in, off[k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (CHECK && g0 + (uint32_t)k * T >= ngroups) continue;
+        const uint32_t px[4] = {p[k].x, p[k].y, p[k].z, p[k].w};
+        uint32_t o[4];
+        if (odd[k]) {
+            const ChromaTerm t = chroma_term<ROUND, FMT>(cpx[k], a.mcb, a.mcr);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = finish<FMT>(px[i], a.my, t);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; g += HH) {
+                const ChromaTerm t = chroma_term<ROUND, FMT>(px[g], a.mcb, a.mcr);
+#pragma unroll
+                for (int i = g; i < g + HH; ++i) o[i] = finish<FMT>(px[i], a.my, t);
+            }
+        }
+        const u32x4 ov = {o[0], o[1], o[2], o[3]};
+        out4<NT>(a, out, oo[k], ov);
+    }
+    if (!CHECK) keep_tail_apart();
+}
+
+template <int ROUND, int FMT, int HH, int VV, bool NT>
+__global__ void __launch_bounds__(256) k_f1flat(KArgs a)
+{
+    pin_args(a);
+    const uint32_t T = (uint32_t)a.bdx;
+    const uint32_t ngroups = ((uint32_t)a.W >> 2) * (uint32_t)a.H;
+    const uint32_t b0 = blockIdx.x * (T * 4u);
+    const gin_t in = frame_in(a);
+    const gout_t out = frame_out(a);
+    if (b0 + T * 4u <= ngroups) f1flat_body<ROUND, FMT, HH, VV, NT, false>(a, in, out, b0 + threadIdx.x, T, ngroups);
+    else                        f1flat_body<ROUND, FMT, HH, VV, NT, true>(a, in, out, b0 + threadIdx.x, T, ngroups);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -700,7 +776,7 @@ __global__ void __launch_bounds__(64) k_debug_probe(KArgs a, int64_t off, uint32
 // ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
-enum Family { FAM_F1X4, FAM_DEC, FAM_DEC2V1, FAM_DEC2V2, FAM_GENERIC, FAM_AVG, FAM_AVG_GENERIC, FAM_DECFLAT };
+enum Family { FAM_F1X4, FAM_DEC, FAM_DEC2V1, FAM_DEC2V2, FAM_GENERIC, FAM_AVG, FAM_AVG_GENERIC, FAM_DECFLAT, FAM_F1FLAT };
 
 } // namespace csic
 
@@ -738,6 +814,19 @@ static KernelFn pick_f1x4(int h, int v)
     if (h == 1) return k_f1x4<ROUND, FMT, 1, 2, NT>;
     if (h == 2) return k_f1x4<ROUND, FMT, 2, 2, NT>;
     return k_f1x4<ROUND, FMT, 4, 2, NT>;
+}
+
+template <int ROUND, int FMT, bool NT>
+static KernelFn pick_f1flat(int h, int v)
+{
+    if (v == 1) {
+        if (h == 1) return k_f1flat<ROUND, FMT, 1, 1, NT>;
+        if (h == 2) return k_f1flat<ROUND, FMT, 2, 1, NT>;
+        return k_f1flat<ROUND, FMT, 4, 1, NT>;
+    }
+    if (h == 1) return k_f1flat<ROUND, FMT, 1, 2, NT>;
+    if (h == 2) return k_f1flat<ROUND, FMT, 2, 2, NT>;
+    return k_f1flat<ROUND, FMT, 4, 2, NT>;
 }
 
 constexpr int DEC_K = 4;
@@ -900,7 +989,16 @@ static void select_rf(csic_plan *pl)
     // f = 1: the 16-byte kernel wins whenever it applies (8192^2: 4:4:4 84.0 vs 88.0 us, 4:2:0 84.5 vs 85.9 us for
     // the 4-byte k_dec<f1>, which serves the other widths / alignments; variant 4 forces k_dec<f1> for A/B).
     const bool f1x4_ok = !pl->force_generic && !ycc_in && !pl->no_vec && g.f == 1 && g.W % 4 == 0;
-    if (f1x4_ok && (pl->variant != 4 || !dec_fast_ok(g))) {
+    if (f1x4_ok && pl->variant != 11 && pl->variant != 4) {
+        // the flat mapping (round 4): ahead of k_f1x4 at every chroma mode and on 10 of 12 frame sizes -- 8192x8192 4:2:0 77.0 ->
+        // 79.3 %, 4:2:2 77.5 -> 80.3 %, 4:4:4 78.8 -> 79.8 %, 4:1:0 76.5 -> 79.5 %, 4096x4096 76.5 -> 79.1 %, 1000x1000 76.6 -> 78.9 %;
+        // level (-0.5) on 3840x2160 and 1920x1080 (profiles/r04_f1flat_ab.log).  CSIC_TUNE_VARIANT 11 keeps k_f1x4 for A/B.
+        pl->fam = FAM_F1FLAT;
+        pl->fn = nt ? pick_f1flat<ROUND, FMT, true>(g.h, g.v) : pick_f1flat<ROUND, FMT, false>(g.h, g.v);
+        pl->units_per_row = g.W / 4;
+        pl->k_per_lane = 1;
+        snprintf(pl->name, sizeof pl->name, "k_f1flat<%s,%s,h%d,v%d,%s>", rn, fn, g.h, g.v, ntn);
+    } else if (f1x4_ok && (pl->variant != 4 || !dec_fast_ok(g))) {
         pl->fam = FAM_F1X4;
         pl->fn = nt ? pick_f1x4<ROUND, FMT, true>(g.h, g.v) : pick_f1x4<ROUND, FMT, false>(g.h, g.v);
         pl->units_per_row = g.W / 4;
@@ -1016,7 +1114,7 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
         return set_error(CSIC_EINVAL_SIZE, "row pitch (%d, %d px) smaller than the frame width (%d, %d px)", ip, op, g.W, g.Wo);
     // (k_avg takes any 4-byte alignment: gfx950 executes its 16-byte accesses at any dword address, tools/ubench_unaligned.hip;
     // the others keep the rule because their 4-byte fallbacks are as fast as a misaligned vector access would be)
-    const bool vec = (fam == FAM_F1X4 || fam == FAM_DEC2V1 || fam == FAM_DEC2V2);
+    const bool vec = (fam == FAM_F1X4 || fam == FAM_DEC2V1 || fam == FAM_DEC2V2 || fam == FAM_F1FLAT);
     if (vec && ((align_bits & 15u) || ((ip | op) & 3))) {
         csic_plan tmp = *pl;
         tmp.no_vec = 1;
@@ -1060,6 +1158,15 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
         // every block on the straight-line path (4K f=2: 70 % -> 80 % of HBM peak).  The width only has to
         // be a multiple of the lane-hold distance so that a DPP hold group never straddles two rows.
         bx = dec_block_x(lanes_x, tpb, hold);
+    }
+    if (fam == FAM_F1FLAT) {
+        const int T = forced ? tpb : 64;
+        const int64_t ngroups = (int64_t)(g.W / 4) * g.H, per_block = (int64_t)T * 4;
+        d->block = dim3((unsigned)T, 1, 1);
+        a.bdx = T; a.bdy = 1; a.row_step = 1;
+        d->grid = dim3((unsigned)((ngroups + per_block - 1) / per_block), 1, (unsigned)nframes);
+        d->fn = fn;
+        return CSIC_OK;
     }
     if (fam == FAM_DECFLAT) {
         // lanes over the flat decimated stream: blocks of whole waves, K indices per lane spaced by the block size

@@ -79,7 +79,7 @@ for it in range(260):
     p = orc.OracleParams(width=W, height=H, chroma_a=a, chroma_b=b, y_bits=7, cb_bits=6, cr_bits=5, factor=f, op=op)
     cp = csic.make_c_params(W, H, a, b, 7, 6, 5, f, op, out_format=2 if planar else 0, sampling=csic.Sampling.AVG if avg else csic.Sampling.HOLD_DECIMATE)
     with csic.Plan(cp, 0) as pl:
-        for variant in (0, 5, 7, 9, 10) if not avg else (0, 8):
+        for variant in (0, 5, 7, 9, 10, 11) if not avg else (0, 8):
             pl.tune(N.TUNE_VARIANT, variant)
             kernels.add(pl.kernel_name.split("<")[0])
             want = orc.process(p, argb, form="avg" if avg else "stream")
@@ -97,5 +97,5 @@ print("clean", len(kernels), sorted(kernels))
 def test_every_kernel_family_runs_clean_under_the_range_checks():
     r = _child(SAMPLE, timeout=900)
     assert r.returncode == 0 and "clean" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    for fam in ("k_avg", "k_dec", "k_decflat", "k_f1x4", "k_flatgen", "k_generic", "k_planar_flat", "k_planar_strided", "k_planar_avg_f1", "k_planar_avg_gen"):
+    for fam in ("k_avg", "k_dec", "k_decflat", "k_f1flat", "k_f1x4", "k_flatgen", "k_generic", "k_planar_flat", "k_planar_strided", "k_planar_avg_f1", "k_planar_avg_gen"):
         assert f"'{fam}'" in r.stdout, (fam, r.stdout)

@@ -100,7 +100,7 @@ def test_fused_graph_unaligned_frames_and_stream_capture(csic, oracle):
     host = [oracle.synth_frame(W * H, 300 + k) for k in range(n)]
     want = [oracle.process(_oparams(oracle, W, H, 2, 2, (6, 5, 5), 1), h, form="closed") for h in host]
     with csic.Plan(cp, 0) as pl:
-        assert pl.kernel_name.startswith("k_f1x4")
+        assert pl.kernel_name.startswith("k_f1flat")
         pool = torch.zeros(n * (W * H + 1) + 1, dtype=torch.int32, device="cuda:0")
         d_ins = []
         for k, h in enumerate(host):

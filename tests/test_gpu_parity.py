@@ -71,7 +71,7 @@ def test_random_shapes_vs_oracle(csic, oracle, seed):
             seen.add(pl.kernel_name.split("<")[0])
             got = pl.process_host(argb)
             assert np.array_equal(got, want), (pl.kernel_name, W, H, a, b, bits, f, op, rounding, fmt)
-            for variant in (1, 2, 4, 5, 6):             # 16-byte-load f=2 variants; 4 = k_dec<f1> instead of k_f1x4; 5 / 6 = never /
+            for variant in (1, 2, 4, 5, 6, 11):         # 16-byte-load f=2 variants; 4 = k_dec<f1> instead of k_f1flat; 11 = k_f1x4; 5 / 6 = never /
                 pl.tune(csic._native.TUNE_VARIANT, variant)   # always k_decflat where it applies
                 seen.add(pl.kernel_name.split("<")[0])
                 assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
@@ -84,7 +84,7 @@ def test_random_shapes_vs_oracle(csic, oracle, seed):
             pl.tune(csic._native.TUNE_FORCE_GENERIC, 1)
             assert pl.kernel_name.startswith("k_generic")
             assert np.array_equal(pl.process_host(argb), want), (pl.kernel_name, W, H)
-    assert {"k_f1x4", "k_dec", "k_decflat", "k_generic"} <= seen
+    assert {"k_f1flat", "k_f1x4", "k_dec", "k_decflat", "k_generic"} <= seen
 
 
 @pytest.mark.parametrize("a,b", [(4, 4), (2, 2), (2, 0), (1, 1), (1, 0), (4, 0)])
@@ -133,7 +133,7 @@ def test_cfg2_128_422_q8(csic, oracle, input_images):
     argb = oracle.rgb_to_argb(input_images["in128"])
     want = oracle.process(_oparams(oracle, 128, 128, 2, 2, (3, 3, 2)), argb)
     with _plan(csic, 128, 128, 2, 2, (3, 3, 2)) as pl:
-        assert pl.kernel_name.startswith("k_f1x4")           # 4:2:2 (v = 1): the 16-byte kernel
+        assert pl.kernel_name.startswith("k_f1flat")         # 4:2:2 (v = 1): the 16-byte kernel
         assert np.array_equal(pl.process_host(argb), want)
 
 

@@ -49,7 +49,7 @@ while time.time() < t_end:
     cp = csic.make_c_params(W, H, a, b, *bits, f, op, rounding=rounding, out_format=fmt,
                             sampling=1 if avg else 0, in_format=1 if ycc_in else 0)
     with csic.Plan(cp, 0) as pl:
-        knobs = [(None, None), (N.TUNE_NONTEMPORAL, 0), (N.TUNE_NO_VECTOR, 1), (N.TUNE_VARIANT, int(rng.integers(1, 9))),
+        knobs = [(None, None), (N.TUNE_NONTEMPORAL, 0), (N.TUNE_NO_VECTOR, 1), (N.TUNE_VARIANT, int(rng.integers(1, 12))),
                  (N.TUNE_FORCE_GENERIC, 1)]
         for knob, val in knobs[: 1 + int(rng.integers(0, len(knobs)))]:
             if knob is not None:
