@@ -1114,14 +1114,14 @@ def main(argv=None):
         safe_side("direct_dispatch", headline_mode, "direct")
     profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
     # `pitched`: the same frames laid out at the row pitches csic_plan_preferred_pitch names (the caller's choice of layout; the
-    # headline stays packed).  Measured where the rule pads (factor-1 plans: 8k_420_f1, 8k_444_f1); where it names the packed
-    # layout (cfg 4, cfg 5: decimating plans) the object says so and nothing is run twice.
+    # headline stays packed).  Measured where the rule pads; where it names the packed layout -- every plan on the round-4
+    # kernels -- the object says so and nothing is run twice.
     if world == 1 and args.stripe_of <= 1 and issue == "serial" and not args.pitch_pad and not head["planar"] \
             and not args.per_frame_graph and not args.busy_streams and args.streams <= 1 and not args.no_pitched and args.frames_per_step <= 0:
         if head["preferred_pitch"] == (W, head["out_w"]):
             sides["pitched"] = {"in_pitch_px": W, "out_pitch_px": head["out_w"],
-                                "packed": "csic_plan_preferred_pitch names the packed layout for this plan: with a decimating factor no padded "
-                                          "layout beats packed rows on these kernels (profiles/r04_probe_pitch.jsonl)"}
+                                "packed": "csic_plan_preferred_pitch names the packed layout for this plan: no padded layout beats packed rows "
+                                          "on these kernels (profiles/r04_probe_pitch.jsonl, r04_probe_pitch_f1flat.jsonl)"}
         elif not profiled:
             safe_side("pitched", headline_mode, "serial", preferred_pitch=True)
             if isinstance(sides.get("pitched"), dict) and "value" in sides["pitched"]:

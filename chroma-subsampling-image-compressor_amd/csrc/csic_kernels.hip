@@ -1456,15 +1456,18 @@ int csic_plan_preferred_pitch(const csic_plan *plan, int32_t *in_pitch_px, int32
 {
     if (!plan || !in_pitch_px || !out_pitch_px) return set_error(CSIC_EINVAL_NULL, "argument is NULL");
     const Geometry &g = plan->g;
-    // Measured on the round-4 kernels over 2048- to 16384-pixel rows (tools/probe_pitch2.py, profiles/r04_probe_pitch.jsonl):
-    //  * factor 1 (input and output rows equally long, every row read AND written): 1 KiB of padding on both sides is worth
-    //    2-5 points at every width (8192: 76.2 -> 80.3 %, 16384: 76.4 -> 81.5 %, 2048: 75.8 -> 78.7 %, 5120: 76.4 -> 80.5 %);
-    //  * factor 2 / 4 / 8: packed rows are as fast as any padded layout (8192 f = 2: 82.9 % packed, 82.0-82.8 % padded; f = 8:
-    //    79.5 % packed, 74.5-77.7 % padded) -- the gain round 2 measured for k_dec (+2-4 points at 8192) went away with
-    //    k_decflat's flat mapping, and small pads (16-64 pixels) lose up to 10 points.
-    const bool pad = g.f == 1 && plan->p.out_format != CSIC_FMT_PLANAR && g.W >= 1024;
-    *in_pitch_px = pad ? g.W + 256 : g.W;
-    *out_pitch_px = pad ? g.Wo + 256 : g.Wo;
+    // Measured on the round-4 kernels over 2048- to 16384-pixel rows x factors 1 / 2 / 4 / 8 x 13 (input pad, output pad) pairs
+    // (tools/probe_pitch2.py, profiles/r04_probe_pitch.jsonl): packed rows are as fast as any padded layout, at every factor.
+    //  * factor 2 / 4 / 8 (k_decflat / k_dec): 8192 f = 2: 82.9 % packed, 82.0-82.8 % padded; f = 8: 79.5 % packed, 74.5-77.7 %
+    //    padded -- the +2-4 points round 2 measured for k_dec at 8192 went away with k_decflat's flat mapping;
+    //  * factor 1: k_f1x4 (rounds 1-3) did gain 2-5 points from 1 KiB of padding on both sides (8192: 76.2 -> 80.3 %), and the
+    //    first round-4 rule said so; k_f1flat reaches that rate on PACKED rows (79.7 / 79.1 %) and loses two points on padded
+    //    ones (77.6 %: rows 3-4 of profiles/r04_bench_all_configs.jsonl as first measured with it; r04_probe_pitch_f1flat.jsonl).
+    //  * pads of 16-64 pixels lose up to 10 points everywhere.
+    // What looked like a property of the DRAMs was a property of two kernels' block-to-address mappings.  The answer is therefore
+    // "packed" for every plan; the entry point stays so that a caller need not know that, and so that a future kernel can change it.
+    *in_pitch_px = g.W;
+    *out_pitch_px = g.Wo;
     clear_error();
     return CSIC_OK;
 }

@@ -269,14 +269,12 @@ int  csic_reconstruct_device(csic_plan *plan, const void *d_planar, void *d_out,
                              void *hip_stream);
 
 /* Row pitches, in pixels, at which frames of this plan stream fastest when the CALLER lays them out
- * (csic_process_pitched_device): the width itself unless padding the rows is measured to pay.  Measured on 2048- to
- * 16384-pixel rows (tools/probe_pitch2.py, profiles/r04_probe_pitch.jsonl): at factor 1 -- input and output rows equally
- * long, every row read and written -- 256 pixels (1 KiB) of padding on both sides are worth 2-5 points of the HBM roofline
- * at every width (8192x8192 4:2:0: 76.2 -> 80.3 %); with a decimating factor packed rows are as fast as any padded layout
- * (the +2-4 points round 2 measured for 8192-pixel rows went away with the flat mapping of k_decflat), and pads of 16-64
- * pixels lose up to 10 points.  So: width + 256 for factor-1 plans of at least 1024-pixel rows, the width otherwise.
- * Packed rows remain the default of every entry point and the layout of the headline measurement; this only tells a caller
- * that owns its surfaces what to allocate. */
+ * (csic_process_pitched_device).  Measured on 2048- to 16384-pixel rows x every factor x 13 (input pad, output pad) pairs
+ * (tools/probe_pitch2.py, profiles/r04_probe_pitch.jsonl, r04_probe_pitch_f1flat.jsonl): on the round-4 kernels packed rows are
+ * as fast as any padded layout -- the gains rounds 2 and 3 saw from 1 KiB of padding (8192-pixel rows: +2-4 points at factor
+ * 2 / 8 with k_dec, +2-5 points at factor 1 with k_f1x4) were properties of those kernels' block-to-address mappings and went
+ * away with the flat mappings of k_decflat and k_f1flat; pads of 16-64 pixels lose up to 10 points.  So this returns the
+ * widths themselves today.  It exists so that a caller that owns its surfaces asks instead of guessing. */
 int  csic_plan_preferred_pitch(const csic_plan *plan, int32_t *in_pitch_px, int32_t *out_pitch_px);
 
 /* ---- the range-checking build (diagnostics) ----------------------------------------------------------------------

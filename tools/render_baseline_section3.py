@@ -78,9 +78,14 @@ New in round 4 (DESIGN.md §0):
   rule — so the "aligned" neighbours are themselves 9–13 × faster than they were: `profiles/r04_avg_edge_ab.log`, which also
   records the four placements of the edge work that were measured.) Headline AVG shape (row 5): {pct(5):.1f} % with packed 16-bit
   chroma sums (round 3: 74.5 %); traffic {r('avg_8k_420_sf2'):.4f} ×.
-* rows 3–4 carry `pitched`: the same frames with rows at `csic_plan_preferred_pitch` (1 KiB of padding for factor-1 plans):
-  {100 * rows[2]['pitched']['roofline_frac_rank0']:.1f} % and {100 * rows[3]['pitched']['roofline_frac_rank0']:.1f} % against {pct(3):.1f} % and {pct(4):.1f} % packed; for decimating plans the rule names the packed layout (cfg 4, cfg 5: the
-  object says so) — `profiles/r04_probe_pitch.jsonl` (24 width × factor combinations × 13 pad pairs).
+* rows 3–4, 7, 14 — **a faster factor-1 kernel**: `k_f1flat` (groups of 4 pixels over the flat frame, 4 groups per lane spaced by a
+  one-wave block — the mapping the planar kernel found) replaces `k_f1x4`: 8192×8192 4:4:4 {pct(3):.1f} %, 4:2:0 + Q8 {pct(4):.1f} % (round 3:
+  79.0 / 76.9 %), 128×128 at 4096 frames per launch {pct(14):.1f} % (77.7 %); A/B on one box over four chroma modes and twelve sizes:
+  `profiles/r04_f1flat_ab.log`.
+* **row pitch**: `csic_plan_preferred_pitch` answers "packed" for every plan — measured over 6 widths × 4 factors × 13 pad pairs
+  (`profiles/r04_probe_pitch.jsonl`, and `r04_probe_pitch_f1flat.jsonl` for factor 1 on the final kernel): the +2–5 points that
+  1 KiB of row padding gave rounds 2–3's kernels (`k_dec` at f = 2 / 8, `k_f1x4` at f = 1) were properties of those kernels'
+  block-to-address mappings and went away with the flat mappings; the lines' `pitched` object says so.
 
 Rows 7–8 are BASELINE configs[1] and [2] exactly as specified — one 64 KiB / 1 MiB frame per launch, launch-bound — and rows
 14–15 the same kernels at 4096 / 1024 frames per launch, where the roofline fraction is about the kernel: batch small frames
