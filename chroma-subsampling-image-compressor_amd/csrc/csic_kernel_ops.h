@@ -199,11 +199,16 @@ template <int FMT>
 __device__ __forceinline__ uint32_t finish_y(uint32_t y, const ChromaTerm &t)
 {
     if (FMT == F_ARGB) {
+        // clamp(x >> 8, 0, 255) is byte 1 of clamp(x, 0, 65535) -- x < 0 gives 0, x > 65535 gives 0xFFFF -- so the three shifts
+        // and the shift-or packing become one v_med3_i32 per channel and two v_perm_b32 for the pixel (selector 0x0c = 0x00,
+        // 0x0d = 0xFF): 8 VALU per pixel instead of 13 (round 4; the headline kernel: 432 -> 400 VALU instructions over its two bodies).  Checked on
+        // all 2^24 (Y, Cb, Cr) by tests/test_gpu_parity.py::test_exhaustive_cube.
         const int yy = __mul24((int)y, 298);
-        const int r = clamp_u8((yy + t.kr) >> 8);
-        const int g = clamp_u8((yy + t.kg) >> 8);
-        const int b = clamp_u8((yy + t.kb) >> 8);
-        return 0xFF000000u | ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;
+        const uint32_t r = (uint32_t)min(max(yy + t.kr, 0), 65535);
+        const uint32_t g = (uint32_t)min(max(yy + t.kg, 0), 65535);
+        const uint32_t b = (uint32_t)min(max(yy + t.kb, 0), 65535);
+        const uint32_t gb = __builtin_amdgcn_perm(g, b, 0x0c0c0501u);           // { b.byte1, g.byte1, 0, 0 }
+        return __builtin_amdgcn_perm(r, gb, 0x0d050100u);                       // { b, g, r.byte1, 0xFF }
     } else {
         return y | t.ycc_hi;
     }

@@ -392,7 +392,10 @@ __device__ __forceinline__ void recon_slow(const PExtra &e, gcbyte_t fb, gout_t 
     else for (uint32_t q = 0; q < cnt; ++q) out[j0 + q] = o[q];
 }
 
-constexpr int RECON_K = 4;
+#ifndef CSIC_RECON_K
+#define CSIC_RECON_K 4
+#endif
+constexpr int RECON_K = CSIC_RECON_K;
 
 // K groups per lane spaced by the block size: all their loads (one Y dword and the group's chroma samples each) are in flight
 // before the first inverse transform starts.  The first version took one group per lane -- 8 bytes in flight per lane -- and
