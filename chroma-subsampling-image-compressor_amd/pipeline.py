@@ -27,7 +27,8 @@ class FramePipeline:
         N.check(N.lib().csic_pipeline_create(plan._h, self.depth, C.byref(self._h)))
         N.check(N.lib().csic_pipeline_set_mode(self._h, N.PIPELINE_ZERO_COPY if zero_copy else N.PIPELINE_STAGED))
         self._in_shape = (plan.height, plan.width)
-        self._out_shape = (plan.out_height, plan.out_width)
+        # a planar plan hands back its planar frame buffer (bytes; Plan.split_planar cuts it into the three planes)
+        self._out_shape = (plan.planar_layout.frame_bytes // 4,) if plan.planar else (plan.out_height, plan.out_width)
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -62,12 +63,13 @@ class FramePipeline:
         return t.value
 
     def collect(self) -> Tuple[int, np.ndarray]:
-        """Waits for the oldest submitted frame -> (ticket, (Ho, Wo) uint32 view of its PINNED output).
-        The view is valid until that slot is submitted again (depth submissions later)."""
+        """Waits for the oldest submitted frame -> (ticket, (Ho, Wo) uint32 view of its PINNED output; for a planar plan the
+        uint8 view of its planar frame buffer).  The view is valid until that slot is submitted again (depth submissions later)."""
         p = C.POINTER(C.c_uint32)()
         t = C.c_int64()
         N.check(N.lib().csic_pipeline_collect(self._h, C.byref(p), C.byref(t)))
-        return t.value, np.ctypeslib.as_array(p, shape=self._out_shape)
+        out = np.ctypeslib.as_array(p, shape=self._out_shape)
+        return t.value, (out.view(np.uint8) if self.plan.planar else out)
 
     def run(self, frames: Iterable[np.ndarray]) -> Iterator[np.ndarray]:
         """Streams `frames` ((H, W) uint32 ARGB arrays) through the pipeline, keeping up to `depth` in

@@ -259,8 +259,9 @@ int  csic_process_pitched_device(csic_plan *plan, const void *d_in, int32_t in_p
                                  int32_t out_pitch_px, int32_t nframes, void *hip_stream);
 
 /* With out_format = CSIC_FMT_PLANAR, d_out of csic_process_device / csic_process_batch_device is a planar frame buffer of
- * csic_planar_layout.frame_bytes bytes per frame (256-byte aligned).  Row pitches, frame graphs, the host-frame pipeline,
- * the file pools and csic_multi_* take packed formats only (CSIC_EINVAL_FORMAT otherwise).
+ * csic_planar_layout.frame_bytes bytes per frame (256-byte aligned); csic_process_host and csic_pipeline_* hand the same
+ * buffer to the host.  Row pitches, frame graphs, the file pools and csic_multi_* take packed formats only
+ * (CSIC_EINVAL_FORMAT otherwise).
  *
  * csic_reconstruct_device: `nframes` planar frames of `plan`'s parameters (the plan may have any out_format: only its
  * parameters matter) -> packed pixels, out_format = CSIC_FMT_ARGB8888 or CSIC_FMT_YCBCR888X, out_width * out_height per
@@ -441,8 +442,10 @@ int  csic_png_write_argb(const char *path, const uint32_t *src, int32_t width, i
  *                                 when every slot still holds an uncollected frame.
  *   csic_pipeline_submit        : enqueue H2D + kernel + D2H for the acquired buffer (asynchronous).
  *   csic_pipeline_collect       : wait for the OLDEST submitted frame; *host_out points at its pinned
- *                                 output (out_width*out_height pixels), valid until that slot is submitted
- *                                 again.  Frames complete in submission order; *ticket counts from 0.
+ *                                 output (out_width*out_height pixels; for a CSIC_FMT_PLANAR plan the planar
+ *                                 frame buffer of csic_planar_layout_of, frame_bytes long -- 1.5 bytes per
+ *                                 pixel instead of 4 on the way back for 4:2:0), valid until that slot is
+ *                                 submitted again.  Frames complete in submission order; *ticket counts from 0.
  * The plan must outlive the pipeline.  Not thread-safe (one producer/consumer thread). */
 typedef struct csic_pipeline csic_pipeline;
 int  csic_pipeline_create(csic_plan *plan, int32_t depth, csic_pipeline **out);

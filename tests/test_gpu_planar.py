@@ -205,8 +205,6 @@ def test_planar_is_refused_where_packed_pixels_are_expected(csic, oracle):
             N.check(lib.csic_frame_graph_create_ex(pl._h, pin, pout, 1, 0, N.FRAME_GRAPH_FUSED, C.byref(h)))
         with pytest.raises(csic.IllegalArgumentException, match="pitch"):
             N.check(lib.csic_process_pitched_device(pl._h, C.c_void_p(d_in.data_ptr()), 64, C.c_void_p(d_out.data_ptr()), 64, 1, None))
-        with pytest.raises(csic.IllegalArgumentException, match="PLANAR"):
-            csic.FramePipeline(pl, depth=1)
         with pytest.raises(csic.IllegalArgumentException):          # a misaligned planar buffer
             N.check(lib.csic_process_device(pl._h, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr() + 4), None))
         with pytest.raises(csic.IllegalArgumentException):
@@ -214,6 +212,26 @@ def test_planar_is_refused_where_packed_pixels_are_expected(csic, oracle):
         assert pl.preferred_pitch == (64, 64)
     with pytest.raises(csic.IllegalArgumentException):
         csic.MultiDeviceCompressor(csic.make_c_params(64, 16, 2, 0, 8, 8, 8, 1, CSQ, out_format=csic.PixelFormat.PLANAR), [0])
+
+
+@pytest.mark.parametrize("zero_copy", [True, False])
+def test_planar_through_the_host_frame_pipeline(csic, oracle, zero_copy):
+    """csic_pipeline_* with a CSIC_FMT_PLANAR plan: pinned ARGB frames in, the planar frame buffer back (1.5 bytes per pixel on the
+    return leg for 4:2:0) -- the planes against the oracle's planar form, frame by frame, more frames than slots, both modes."""
+    rng = np.random.default_rng(77)
+    for (W, H, a, b, f, order, avg) in ((64, 16, 2, 0, 1, CSQ, False), (250, 37, 2, 0, 2, CSQ, False), (96, 20, 2, 2, 2, (1, 3, 2), False),
+                                        (128, 32, 2, 0, 2, CSQ, True)):
+        frames = [rng.integers(0, 1 << 32, (H, W), dtype=np.uint32) for _ in range(5)]
+        op_ = oracle.OracleParams(width=W, height=H, chroma_a=a, chroma_b=b, y_bits=7, cb_bits=5, cr_bits=6, factor=f, op=order, rounding=0)
+        cp = csic.make_c_params(W, H, a, b, 7, 5, 6, f, order, out_format=csic.PixelFormat.PLANAR, sampling=1 if avg else 0)
+        with csic.Plan(cp, 0) as pl, csic.FramePipeline(pl, depth=2, zero_copy=zero_copy) as pipe:
+            outs = list(pipe.run(frames))
+            assert len(outs) == len(frames)
+            for fr, got in zip(frames, outs):
+                assert got.dtype == np.uint8 and got.size == pl.planar_layout.frame_bytes
+                _, y_o, cb_o, cr_o = oracle.planar(op_, fr.reshape(-1), avg=avg)
+                y, cb, cr = pl.split_planar(got)
+                assert np.array_equal(y, y_o) and np.array_equal(cb, cb_o) and np.array_equal(cr, cr_o), (W, H, a, b, f, order, avg)
 
 
 def test_preferred_pitch_rule(csic):
