@@ -99,6 +99,30 @@ template <bool NT> __device__ __forceinline__ void out2(const KArgs &a, gout_t o
 template <bool NT> __device__ __forceinline__ void out4(const KArgs &a, gout_t out, int64_t off, u32x4 v)
 { CSIC_CHECK(off >= 0 && off + 4 <= out_extent(a)); (void)a; st4<NT>(out + off, v); }
 
+// The same with a 32-bit pixel offset, for kernels that are only launched on frames whose extents fit 2^30 pixels (the flat
+// kernels): the byte offset is a uint32, and "uniform base + zero-extended 32-bit lane offset" is the saddr form of
+// global_load / global_store -- the frame base stays in SGPRs and no lane computes a 64-bit address.
+template <bool NT> __device__ __forceinline__ uint32_t in1n(const KArgs &a, gin_t in, uint32_t off)
+{
+    CSIC_CHECK((int64_t)off + 1 <= in_extent(a)); (void)a;
+    return ld1<NT>((gin_t)((const char CSIC_GLOBAL *)in + (uint64_t)(off << 2)));
+}
+template <bool NT> __device__ __forceinline__ u32x4 in4n(const KArgs &a, gin_t in, uint32_t off)
+{
+    CSIC_CHECK((int64_t)off + 4 <= in_extent(a)); (void)a;
+    return ld4<NT>((gin_t)((const char CSIC_GLOBAL *)in + (uint64_t)(off << 2)));
+}
+template <bool NT> __device__ __forceinline__ void out4n(const KArgs &a, gout_t out, uint32_t off, u32x4 v)
+{
+    CSIC_CHECK((int64_t)off + 4 <= out_extent(a)); (void)a;
+    st4<NT>((gout_t)((char CSIC_GLOBAL *)out + (uint64_t)(off << 2)), v);
+}
+template <bool NT> __device__ __forceinline__ void out1n(const KArgs &a, gout_t out, uint32_t off, uint32_t v)
+{
+    CSIC_CHECK((int64_t)off + 1 <= out_extent(a)); (void)a;
+    st1<NT>((gout_t)((char CSIC_GLOBAL *)out + (uint64_t)(off << 2)), v);
+}
+
 // A kernel that picks, block-uniformly, between a straight-line body and a bounds-checked copy of it ends both with the same
 // store; LLVM's SimplifyCFG then sinks that store into a common tail -- and the hardware waits there with s_waitcnt vmcnt(0) for
 // every earlier load AND store of the wave before it may issue the last one.  On the headline kernel that was 1 us per launch

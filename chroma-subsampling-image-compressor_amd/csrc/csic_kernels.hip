@@ -95,18 +95,33 @@ __device__ __forceinline__ void f1flat_body(const KArgs &a, gin_t in, gout_t out
 {
     constexpr int K = 4;
     u32x4 p[K];
-    uint32_t cpx[K], row[K];
-    int64_t off[K], oo[K];
+    uint32_t cpx[K], row[K], off[K], oo[K];
     bool odd[K];
+    // 32-bit offsets and stepping instead of K divisions, as in decflat_body: T groups = 4 T pixels = qT rows + rT columns
+    const uint32_t W = (uint32_t)a.W, ip = (uint32_t)a.ip, op = (uint32_t)a.op;
+    const uint32_t qT = (uint32_t)(((uint64_t)(4u * T) * a.mW) >> a.kW), rT = 4u * T - qT * W;
+    const uint32_t in_n = qT * ip + rT, in_w = in_n + ip - W, out_n = qT * op + rT, out_w = out_n + op - W;
+    uint32_t r = 0, col = 0, io = 0, ooff = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t g = CHECK ? min(g0 + (uint32_t)k * T, ngroups - 1u) : g0 + (uint32_t)k * T;
-        const uint32_t j0 = 4u * g;
-        row[k] = (uint32_t)(((uint64_t)j0 * a.mW) >> a.kW);
-        const uint32_t col = j0 - row[k] * (uint32_t)a.W;
-        off[k] = (int64_t)row[k] * a.ip + col;
-        oo[k] = (int64_t)row[k] * a.op + col;
-        odd[k] = (VV == 2) && (row[k] & 1u);
+        if (CHECK || k == 0) {
+            const uint32_t g = CHECK ? min(g0 + (uint32_t)k * T, ngroups - 1u) : g0;
+            const uint32_t j0 = 4u * g;
+            r = (uint32_t)(((uint64_t)j0 * a.mW) >> a.kW);
+            col = j0 - __umul24(r, W);
+            io = __umul24(r, ip) + col;                                          // rows and pitches fit 24 bits (prepare_common)
+            ooff = __umul24(r, op) + col;
+        } else {
+            const bool wrap = col + rT >= W;
+            col = wrap ? col + rT - W : col + rT;
+            r += qT + (wrap ? 1u : 0u);
+            io += wrap ? in_w : in_n;
+            ooff += wrap ? out_w : out_n;
+        }
+        row[k] = r;
+        off[k] = io;
+        oo[k] = ooff;
+        odd[k] = (VV == 2) && (r & 1u);
     }
     // 4:x:0 odd rows replay the last sample of the row above: one row-uniform pixel.  Issued AHEAD of the 16-byte stream loads (as
     // in k_f1x4), only by waves that sit on such a row, and once per row a lane visits -- its K groups are T * 4 pixels apart,
@@ -117,12 +132,12 @@ __device__ __forceinline__ void f1flat_body(const KArgs &a, gin_t in, gout_t out
         if (VV == 2) {
             const bool fresh = (k == 0) || row[k] != row[k > 0 ? k - 1 : 0];
             if (__builtin_amdgcn_ballot_w64(odd[k] && fresh) != 0)
-                cpx[k] = in1<false>(a, in, odd[k] ? (int64_t)(row[k] - 1u) * a.ip + a.last_sample_col : off[k]);
+                cpx[k] = in1n<false>(a, in, odd[k] ? __umul24(row[k] - 1u, ip) + (uint32_t)a.last_sample_col : off[k]);
             if (k > 0 && !fresh) cpx[k] = cpx[k - 1];
         }
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) p[k] = in4<NT>(a, in, off[k]);
+    for (int k = 0; k < K; ++k) p[k] = in4n<NT>(a, in, off[k]);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (CHECK && g0 + (uint32_t)k * T >= ngroups) continue;
@@ -141,7 +156,7 @@ __device__ __forceinline__ void f1flat_body(const KArgs &a, gin_t in, gout_t out
             }
         }
         const u32x4 ov = {o[0], o[1], o[2], o[3]};
-        out4<NT>(a, out, oo[k], ov);
+        out4n<NT>(a, out, oo[k], ov);
     }
     if (!CHECK) keep_tail_apart();
 }
@@ -276,26 +291,53 @@ __global__ void __launch_bounds__(256) k_dec(KArgs a)
 // 4, and with HOLD | Wo a hold group never straddles two rows.  SROWS (spatial before chroma, 4:x:0): on an odd chroma row --
 // (ro / F) odd -- every pixel replays the last sample of the chroma row above; lanes of one wave may sit in different rows
 // here, so the held pixel is a per-lane load whose address is SELECTED (own pixel on even rows: a cache hit), not branched on.
+// Addressing (round 4): the flat kernels are launched only for frames whose extents fit 2^30 pixels and whose rows and pitches fit
+// 24 bits (prepare_common sends anything larger to the row kernels), so a pixel's BYTE offset inside its frame is a uint32 and
+// every access takes the "scalar base + 32-bit lane offset" form of global_load / global_store; row * pitch is one full-rate
+// v_mad_u32_u24.  Only the first of a lane's K indices is divided (the exact multiply-shift); the others follow by stepping:
+// T = qT * Wo + rT, so (ro, co) += (qT, rT) with one conditional wrap, and the two offsets advance by one of two wave-uniform
+// strides each.  The straight-line path of the headline kernel: 192 -> 154 VALU instructions per lane (4 output pixels), 64-bit
+// multiply-adds 20 -> 1, quarter-rate v_mul_lo_u32 4 -> 0; k_f1flat 625 -> 601 (16 pixels), k_flatgen 341 -> 299.  Timing is
+// unchanged -- these kernels wait for HBM -- so this buys headroom, not speed (profiles/r04_narrow_offsets_ab.log).  Two things the
+// A/B runs showed on the way: (1) written with plain 32-bit `ro * op + co`, hipcc formed the low half of a v_mad_u64_u32 whose
+// don't-care high addend it parked in the register the lane's FIRST load writes -- a false dependency, an s_waitcnt on that load in
+// front of the fourth load, 79.4 -> 77.1 % on the headline; the 24-bit multiplies leave nothing undefined to park.  (2) Issuing
+// the K loads back to back after ALL the offset arithmetic (a sched_barrier) instead of interleaved with it costs the headline
+// half a point to two points, whichever part of the arithmetic is moved behind the loads.
 template <int ROUND, int FMT, int F, int HOLD, bool SROWS, int K, bool NT, bool CHECK>
 __device__ __forceinline__ void decflat_body(const KArgs &a, gin_t in, gout_t out, uint32_t i0, uint32_t T, uint32_t n)
 {
-    uint32_t px[K], hp[K];
-    int64_t oo[K], ho[K];
+    uint32_t px[K], hp[K], oo[K], ho[K];
     bool odd[K];
+    const uint32_t Wo = (uint32_t)a.Wo, ip = (uint32_t)a.ip, op = (uint32_t)a.op, rstep = (uint32_t)F * ip;
+    // wave-uniform: how far one step of T indices moves (row, column) and the two offsets, without and with a wrap
+    const uint32_t qT = (uint32_t)(((uint64_t)T * a.mWo) >> a.kWo), rT = T - qT * Wo;
+    const uint32_t in_n = qT * rstep + rT * F, in_w = in_n + rstep - Wo * F;
+    const uint32_t out_n = qT * op + rT, out_w = out_n + op - Wo;
+    uint32_t ro = 0, co = 0, yoff = 0, ooff = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        // the frame's last block: clamp instead of branching so that the K loads still issue back to back
-        const uint32_t i = CHECK ? min(i0 + (uint32_t)k * T, n - 1) : i0 + (uint32_t)k * T;
-        const uint32_t ro = (uint32_t)(((uint64_t)i * a.mWo) >> a.kWo);          // i / Wo, exact for i < 2^31
-        const uint32_t co = i - ro * (uint32_t)a.Wo;
-        const int64_t yoff = (int64_t)(ro * F) * a.ip + co * F;
-        px[k] = in1<NT>(a, in, yoff);
-        oo[k] = (int64_t)ro * a.op + co;
+        if (CHECK || k == 0) {
+            // the frame's last block: clamp instead of branching so that the K loads still issue back to back
+            const uint32_t i = CHECK ? min(i0 + (uint32_t)k * T, n - 1) : i0;
+            ro = (uint32_t)(((uint64_t)i * a.mWo) >> a.kWo);                     // i / Wo, exact for i < 2^31
+            co = i - __umul24(ro, Wo);
+            yoff = (__umul24(ro, ip) + co) * F;                                  // rows and pitches fit 24 bits (prepare_common):
+            ooff = __umul24(ro, op) + co;                                        // one full-rate v_mad_u32_u24 each
+        } else {
+            const bool wrap = co + rT >= Wo;
+            co = wrap ? co + rT - Wo : co + rT;
+            ro += qT + (wrap ? 1u : 0u);
+            yoff += wrap ? in_w : in_n;
+            ooff += wrap ? out_w : out_n;
+        }
+        px[k] = in1n<NT>(a, in, yoff);
+        oo[k] = ooff;
         if (SROWS) {
             const int r = (int)(ro >> a.sc_shift);                                // chroma row = ro / F
             odd[k] = (r & a.vmask) != 0;
             const int srow = ((r - 1) << a.sc_shift) + a.bc_row_off;             // decimated row of the held sample
-            ho[k] = odd[k] ? (int64_t)(srow * F) * a.ip + a.bc_col_in : yoff;
+            ho[k] = odd[k] ? __umul24((uint32_t)srow, rstep) + (uint32_t)a.bc_col_in : yoff;
         }
     }
     if (SROWS) {
@@ -304,7 +346,7 @@ __device__ __forceinline__ void decflat_body(const KArgs &a, gin_t in, gout_t ou
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             hp[k] = 0;
-            if (__builtin_amdgcn_ballot_w64(odd[k]) != 0) hp[k] = in1<false>(a, in, ho[k]);
+            if (__builtin_amdgcn_ballot_w64(odd[k]) != 0) hp[k] = in1n<false>(a, in, ho[k]);
         }
     }
     uint32_t cpx[K];
@@ -315,7 +357,7 @@ __device__ __forceinline__ void decflat_body(const KArgs &a, gin_t in, gout_t ou
         if (!CHECK || i0 + (uint32_t)k * T < n) {
             const uint32_t c = (SROWS && odd[k]) ? hp[k] : cpx[k];
             const ChromaTerm t = chroma_term<ROUND, FMT>(c, a.mcb, a.mcr);
-            out1<NT>(a, out, oo[k], finish<FMT>(px[k], a.my, t));
+            out1n<NT>(a, out, oo[k], finish<FMT>(px[k], a.my, t));
         }
     }
     if (!CHECK) keep_tail_apart();
@@ -677,44 +719,53 @@ template <int ROUND, int FMT, int K, bool NT, bool CHECK>
 __device__ __forceinline__ void flatgen_body(const KArgs &a, gin_t in, gout_t out, uint32_t i0, uint32_t T, uint32_t n)
 {
     const int lane = (int)(threadIdx.x & 63u);
-    uint32_t px[K], hp[K];
-    int64_t yo[K], oo[K], ho[K];
+    uint32_t px[K], hp[K], yo[K], oo[K], ho[K];
     int dd[K];
     bool need[K];
+    // 32-bit offsets; (ro, co) of the lane's 2nd..Kth index by stepping, as in decflat_body
+    const uint32_t Wo = (uint32_t)a.Wo, f = (uint32_t)a.f, rstep = f * (uint32_t)a.ip;
+    const uint32_t qT = (uint32_t)(((uint64_t)T * a.mWo) >> a.kWo), rT = T - qT * Wo;
+    uint32_t ro = 0, co = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t j = CHECK ? min(i0 + (uint32_t)k * T, n - 1) : i0 + (uint32_t)k * T;
-        const uint32_t ro = (uint32_t)(((uint64_t)j * a.mWo) >> a.kWo);           // j / Wo, exact for j < 2^31
-        const uint32_t co = j - ro * (uint32_t)a.Wo;
-        yo[k] = (int64_t)(ro * (uint32_t)a.f) * a.ip + co * (uint32_t)a.f;
-        px[k] = in1<NT>(a, in, yo[k]);
-        oo[k] = (int64_t)ro * a.op + co;
+        if (CHECK || k == 0) {
+            ro = (uint32_t)(((uint64_t)j * a.mWo) >> a.kWo);                      // j / Wo, exact for j < 2^31
+            co = j - __umul24(ro, Wo);
+        } else {
+            const bool wrap = co + rT >= Wo;
+            co = wrap ? co + rT - Wo : co + rT;
+            ro += qT + (wrap ? 1u : 0u);
+        }
+        yo[k] = __umul24(ro, rstep) + co * f;                                    // rows, pitches and f * pitch fit 24 bits (prepare_common)
+        px[k] = in1n<NT>(a, in, yo[k]);
+        oo[k] = __umul24(ro, (uint32_t)a.op) + co;
         int r, d;
         if (a.s_first) {                                                          // counters over the decimated stream, width W
             r = (int)(((uint64_t)j * a.mW) >> a.kW);
             d = ((int)j - r * a.W) & a.hmask;
         } else {                                                                  // counters == image coordinates (rows ro * f are sample rows)
             r = 0;
-            d = (int)((co * (uint32_t)a.f) & (uint32_t)a.hmask) >> a.sc_shift;
+            d = (int)((co * f) & (uint32_t)a.hmask) >> a.sc_shift;
         }
         const bool odd = (r & a.vmask) != 0;
         const int src = odd ? (r - 1) * a.W + a.last_sample_col : (int)j - d;    // flat index whose OWN pixel is the chroma source
-        const int sro = (int)(((uint64_t)(uint32_t)src * a.mWo) >> a.kWo), sco = src - sro * a.Wo;
-        ho[k] = (int64_t)(sro * a.f) * a.ip + sco * a.f;
+        const uint32_t sro = (uint32_t)(((uint64_t)(uint32_t)src * a.mWo) >> a.kWo), sco = (uint32_t)src - sro * Wo;
+        ho[k] = __umul24(sro, rstep) + sco * f;
         dd[k] = odd ? 0 : d;
         need[k] = odd || d > lane;                                                // not in a lane of this wave
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         hp[k] = 0;
-        if (__builtin_amdgcn_ballot_w64(need[k]) != 0) hp[k] = in1<false>(a, in, need[k] ? ho[k] : yo[k]);
+        if (__builtin_amdgcn_ballot_w64(need[k]) != 0) hp[k] = in1n<false>(a, in, need[k] ? ho[k] : yo[k]);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t nb = (uint32_t)__shfl((int)px[k], lane - dd[k], 64);       // all lanes take part
         if (!CHECK || i0 + (uint32_t)k * T < n) {
             const ChromaTerm t = chroma_term<ROUND, FMT>(need[k] ? hp[k] : nb, a.mcb, a.mcr);
-            out1<NT>(a, out, oo[k], finish<FMT>(px[k], a.my, t));
+            out1n<NT>(a, out, oo[k], finish<FMT>(px[k], a.my, t));
         }
     }
     if (!CHECK) keep_tail_apart();
@@ -787,6 +838,7 @@ struct csic_plan {
     int variant;
     int force_generic;
     int no_vec;          // 1 = no 16-byte vector kernels (set per launch for pointers that are only 4-byte aligned)
+    int no_flat;         // 1 = no flat kernels (set per launch for frames whose extents pass 2^30 pixels: they address with 32-bit byte offsets)
     int dec_hold;        // k_dec: lane-hold distance of the selected kernel (1, 2 or 4)
     int no_nt;           // 1 = plain (cached) loads/stores instead of non-temporal ones
     int block_threads;   // 0 = default (256); 64 / 128 = smaller blocks (CSIC_TUNE_BLOCK_THREADS)
@@ -989,7 +1041,7 @@ static void select_rf(csic_plan *pl)
     // f = 1: the 16-byte kernel wins whenever it applies (8192^2: 4:4:4 84.0 vs 88.0 us, 4:2:0 84.5 vs 85.9 us for
     // the 4-byte k_dec<f1>, which serves the other widths / alignments; variant 4 forces k_dec<f1> for A/B).
     const bool f1x4_ok = !pl->force_generic && !ycc_in && !pl->no_vec && g.f == 1 && g.W % 4 == 0;
-    if (f1x4_ok && pl->variant != 11 && pl->variant != 4) {
+    if (f1x4_ok && pl->variant != 11 && pl->variant != 4 && !pl->no_flat) {
         // the flat mapping (round 4): ahead of k_f1x4 at every chroma mode and on 10 of 12 frame sizes -- 8192x8192 4:2:0 77.0 ->
         // 79.3 %, 4:2:2 77.5 -> 80.3 %, 4:4:4 78.8 -> 79.8 %, 4:1:0 76.5 -> 79.5 %, 4096x4096 76.5 -> 79.1 %, 1000x1000 76.6 -> 78.9 %;
         // level (-0.5) on 3840x2160 and 1920x1080 (profiles/r04_f1flat_ab.log).  CSIC_TUNE_VARIANT 11 keeps k_f1x4 for A/B.
@@ -1017,7 +1069,7 @@ static void select_rf(csic_plan *pl)
             pl->units_per_row = g.Wo / (pl->variant == 1 ? 2 : 4);
             pl->k_per_lane = 1;
             snprintf(pl->name, sizeof pl->name, "k_dec2v<%s,%s,var%d,%s>", rn, fn, pl->variant, ntn);
-        } else if (g.f >= 2 && g.Wo % hold == 0 && pl->variant != 5 && (pl->variant == 6 || dec_prefers_flat(g, hold))) {
+        } else if (g.f >= 2 && g.Wo % hold == 0 && pl->variant != 5 && !pl->no_flat && (pl->variant == 6 || dec_prefers_flat(g, hold))) {
             // lanes over the flat decimated stream (variant 5 keeps k_dec, variant 6 takes k_decflat wherever it applies: A/B);
             // a hold group must not straddle two rows: hold | Wo (spatial before chroma has that from dec_fast_ok)
             const bool sr = srows && g.v == 2;
@@ -1041,7 +1093,7 @@ static void select_rf(csic_plan *pl)
             snprintf(pl->name, sizeof pl->name, "k_dec<%s,%s,f%d,hold%d,%s,K%d,%s>", rn, fn, g.f, hold,
                      g.f == 1 ? (g.v == 2 ? "v2" : "v1") : srows ? (g.v == 2 ? "s>c,v2" : "s>c") : "c>s", DEC_K, ntn);
         }
-    } else if (!pl->force_generic && !ycc_in && g.f >= 2 && pl->variant != 7) {
+    } else if (!pl->force_generic && !ycc_in && g.f >= 2 && pl->variant != 7 && !pl->no_flat) {
         // what k_dec / k_decflat cannot take (spatial before chroma with f not dividing W or h not dividing Wo; tiny frames with a
         // hold): the general flat kernel; variant 7 keeps the one-pixel-per-lane k_generic for A/B
         pl->fam = FAM_DECFLAT;
@@ -1115,9 +1167,18 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
     // (k_avg takes any 4-byte alignment: gfx950 executes its 16-byte accesses at any dword address, tools/ubench_unaligned.hip;
     // the others keep the rule because their 4-byte fallbacks are as fast as a misaligned vector access would be)
     const bool vec = (fam == FAM_F1X4 || fam == FAM_DEC2V1 || fam == FAM_DEC2V2 || fam == FAM_F1FLAT);
-    if (vec && ((align_bits & 15u) || ((ip | op) & 3))) {
+    // The flat kernels address a pixel by a 32-bit BYTE offset from its frame's base (decflat_body): frames whose extents -- pitch
+    // included -- pass 2^30 pixels (4 GiB) take the row kernels, which keep 64-bit offsets.
+    // (and whose rows and pitch -- times the factor -- fit 24 bits, for the full-rate 24-bit multiplies of the row offsets)
+    const int64_t flat_limit = 1ll << 30;
+    const bool too_wide = (fam == FAM_DECFLAT || fam == FAM_F1FLAT) &&
+                          ((int64_t)(g.H - 1) * ip + g.W > flat_limit || (int64_t)(g.Ho - 1) * op + g.Wo > flat_limit ||
+                           g.H >= (1 << 24) || (int64_t)ip * g.f >= (1 << 24) || op >= (1 << 24));
+    const bool misaligned = vec && ((align_bits & 15u) || ((ip | op) & 3));
+    if (too_wide || misaligned) {
         csic_plan tmp = *pl;
-        tmp.no_vec = 1;
+        if (too_wide) tmp.no_flat = 1;
+        if (misaligned) tmp.no_vec = 1;
         select(&tmp);
         fam = tmp.fam; fn = tmp.fn; units = tmp.units_per_row; kpl = tmp.k_per_lane; dec_hold = tmp.dec_hold;
     }

@@ -443,6 +443,64 @@ def test_frames_beyond_4gib_offsets(csic, oracle):
         _plan(csic, 65536, 32768)                                        # 2^31 pixels: rejected
 
 
+def test_flat_kernels_at_the_4gib_boundary(csic, oracle):
+    """The flat kernels (k_decflat, k_f1flat, k_flatgen) address a pixel by a 32-bit BYTE offset from its frame's base and are
+    launched only while the frame's extents fit 2^30 pixels.  32768 x 32768 is exactly that (the last pixel sits at byte
+    2^32 - 4): the stripe property on the first and last rows, with packed rows and -- one pixel of pitch more, which passes the
+    limit and must take the row kernels -- through csic_process_pitched_device.  (Frames beyond the limit: the test above.)"""
+    import torch
+    W = H = 32768
+    N = csic._native
+    lib = N.lib()
+    sh = C.c_void_p(torch.cuda.current_stream(0).cuda_stream)
+    d_in = torch.empty(W * H + 64 * W, dtype=torch.int32, device="cuda:0")          # room for the pitched case below
+    N.check(lib.csic_synth_frame_device(C.c_void_p(d_in.data_ptr()), W * H + 64 * W, 0, 20250629, sh))
+    rows = 32
+    for (a, b, bits, f, order) in [(2, 0, (3, 3, 2), 1, CSQ), (2, 0, (8, 8, 8), 2, CSQ), (2, 0, (8, 8, 8), 4, (1, 3, 2)), (4, 4, (8, 8, 8), 2, (1, 3, 2))]:
+        with _plan(csic, W, H, a, b, bits, f, order) as big, _plan(csic, W, rows, a, b, bits, f, order) as small:
+            assert big.kernel_name.split("<")[0] in ("k_decflat", "k_f1flat", "k_flatgen"), big.kernel_name
+            d_out = big.process_device(d_in[:W * H])
+            for r0 in (0, H - rows):
+                part = small.process_device(d_in[r0 * W:(r0 + rows) * W].contiguous())
+                torch.cuda.synchronize()
+                assert torch.equal(part, d_out[r0 // f:(r0 + rows) // f]), (a, b, f, order, r0)
+                host = d_in[r0 * W:(r0 + rows) * W].cpu().numpy().view(np.uint32)
+                want = oracle.process(_oparams(oracle, W, rows, a, b, bits, f, order), host, form="closed")
+                assert np.array_equal(part.cpu().numpy().view(np.uint32), want)
+            if f == 2 and order == CSQ:
+                # the same plan on rows pitched by W + 1 pixels: the extent passes 2^30 pixels -> row kernels, same pixels.  Only the
+                # first and last stripes of the pitched layout are filled (and compared): rows r of the pitched view start at r * (W + 1)
+                ip = W + 1
+                d_pin = torch.empty((H - 1) * ip + W, dtype=torch.int32, device="cuda:0")
+                for r0 in (0, H - rows):
+                    for r in range(r0, r0 + rows):
+                        d_pin[r * ip:r * ip + W] = d_in[r * W:(r + 1) * W]
+                d_pout = torch.zeros(big.out_width * big.out_height, dtype=torch.int32, device="cuda:0")
+                N.check(lib.csic_process_pitched_device(big._h, C.c_void_p(d_pin.data_ptr()), ip, C.c_void_p(d_pout.data_ptr()), big.out_width, 1, sh))
+                torch.cuda.synchronize()
+                Wo = big.out_width
+                for r0 in (0, H - rows):
+                    assert torch.equal(d_pout[(r0 // f) * Wo:((r0 + rows) // f) * Wo], d_out.reshape(-1)[(r0 // f) * Wo:((r0 + rows) // f) * Wo]), (f, r0)
+                del d_pin, d_pout
+            del d_out
+
+
+@pytest.mark.parametrize("W,H", [(8, (1 << 24) + 64), ((1 << 24) + 64, 8), (1 << 23, 16), ((1 << 22) + 4, 16)])
+def test_flat_kernels_24_bit_rows_and_pitches(csic, oracle, W, H):
+    """The flat kernels form row * pitch with 24-bit multiplies: frames with 2^24 rows or more, or whose pitch times the factor
+    reaches 2^24 pixels, take the row kernels at launch (prepare_common).  Very tall and very wide frames on both sides of that
+    rule, whole frames against the oracle (67-134 Mpixel each)."""
+    import torch
+    rng = np.random.default_rng(W ^ H)
+    frame = rng.integers(0, 1 << 32, W * H, dtype=np.uint32)
+    d_in = torch.from_numpy(frame.view(np.int32)).cuda()
+    for (a, b, bits, f, order) in [(2, 0, (8, 8, 8), 1, CSQ), (2, 0, (7, 6, 5), 2, CSQ), (2, 2, (8, 8, 8), 4, (1, 3, 2))]:
+        with _plan(csic, W, H, a, b, bits, f, order) as pl:
+            got = pl.process_device(d_in).cpu().numpy().view(np.uint32)
+        want = oracle.process(_oparams(oracle, W, H, a, b, bits, f, order), frame, form="closed")
+        assert np.array_equal(got.reshape(want.shape), want), (W, H, a, b, f, order)
+
+
 # ---- host-frame pipeline (pinned staging, H2D || kernel || D2H) ---------------------------------------
 @pytest.mark.parametrize("zero_copy", [False, True])
 @pytest.mark.parametrize("depth", [1, 2, 4])

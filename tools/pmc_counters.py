@@ -14,7 +14,7 @@ for path in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recurs
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
 for k, cs in acc.items():
-    if "k_synth" in k or "k_copy" in k:
+    if "k_synth" in k or "k_copy" in k or "csic::" not in k:
         continue
     m = {c: sum(v) / len(v) for c, v in cs.items()}
     d = {"means_per_launch": m, "launches_sampled": max(len(v) for v in cs.values())}
