@@ -71,7 +71,7 @@ AVG_CONFIGS = {"avg_8k_420_sf2": CONFIGS["cfg4"], "avg_4k_420_sf4": CONFIGS["cfg
 CONFIGS.update(AVG_CONFIGS)
 # planar output (CSIC_FMT_PLANAR: Y plane + Cb / Cr planes at the chroma sample points only; the reconstruct kernel beside it)
 PLANAR_CONFIGS = {"planar_8k_420_f1": CONFIGS["8k_420_f1"], "planar_8k_420_f1_avg": CONFIGS["8k_420_f1"],
-                  "planar_cfg4": CONFIGS["cfg4"]}
+                  "planar_cfg4": CONFIGS["cfg4"], "planar_cfg4_avg": CONFIGS["cfg4"]}
 CONFIGS.update(PLANAR_CONFIGS)
 CSQ = (3, 1, 2)
 # launches per step (--batch-frames 0): the headline config times batches of frames, each frame its own launch, so that the

@@ -81,6 +81,7 @@ void fill_base_args(const Geometry &g, int32_t ip, int32_t op, KArgs *a);
 // csic_planar.hip: out_format = CSIC_FMT_PLANAR (forward: packed input -> planar frame buffers; name of the kernel a plan takes)
 int planar_forward(const csic_plan *pl, const void *d_in, void *d_planar, int nframes, hipStream_t stream);
 void planar_kernel_name(const csic_plan *pl, char *buf, size_t len);
+int planar_avg_geometry(const csic_plan *pl, int nframes, LaunchDesc *d, bool *tile);   // k_avg's geometry for a planar AVG plan
 void plan_sizes(const csic_plan *pl, size_t *in_px, size_t *out_px);
 int32_t plan_width(const csic_plan *pl);
 void plan_out_dims(const csic_plan *pl, int32_t *wo, int32_t *ho);

@@ -225,7 +225,8 @@ __device__ __forceinline__ uint32_t finish_y(uint32_t y, const ChromaTerm &t)
     if (FMT == F_ARGB) {
         // clamp(x >> 8, 0, 255) is byte 1 of clamp(x, 0, 65535) -- x < 0 gives 0, x > 65535 gives 0xFFFF -- so the three shifts
         // and the shift-or packing become one v_med3_i32 per channel and two v_perm_b32 for the pixel (selector 0x0c = 0x00,
-        // 0x0d = 0xFF): 8 VALU per pixel instead of 13 (round 4; the headline kernel: 432 -> 400 VALU instructions over its two bodies).  Checked on
+        // 0x0d = 0xFF): 8 VALU per pixel instead of 13 (round 4; SQ_INSTS_VALU per wave of the headline kernel 208 -> 192, and 154 with the
+        // flat kernels' 32-bit addressing: profiles/r04_counters.json).  Checked on
         // all 2^24 (Y, Cb, Cr) by tests/test_gpu_parity.py::test_exhaustive_cube.
         const int yy = __mul24((int)y, 298);
         const uint32_t r = (uint32_t)min(max(yy + t.kr, 0), 65535);

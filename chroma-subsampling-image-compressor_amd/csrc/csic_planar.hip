@@ -38,6 +38,7 @@
 #include <cstring>
 
 #include "csic_kernel_ops.h"
+#include "csic_avg_tile.h"
 
 namespace csic {
 
@@ -346,6 +347,69 @@ __global__ void __launch_bounds__(256) k_planar_avg_f1(KArgs a, PExtra e)
     }
 }
 
+// any factor, any shape with a whole tile: k_avg's body (csic_avg_tile.h: 4 x max(f, v) tiles in registers, edge blocks for the
+// cut tiles) computing packed YCbCr -- under AVG every pixel carries its chroma block's average -- with a sink that scatters the
+// bytes into the planes instead of packing pixels: the Y byte of every position, Cb / Cr at the sample points, which the AVG
+// layout puts at every (max(1, h / f))-th column of every (max(1, v / f))-th row of the output (csic.h).  A tile yields 4 / f
+// consecutive positions of max(f, v) / f rows (one position per lane pair at f = 8).  Stores are as wide as the run is long where
+// the plane's rows keep them aligned (wave-uniform), single bytes otherwise.
+template <int LHE, int LVE>
+struct PlanarSink {
+    const PExtra &e;
+    gbyte_t fb;
+    int Wo;
+    // n bytes (n = 1, 2, 4; v holds them little-endian) at byte offset off of the planar frame
+    template <int NB> __device__ __forceinline__ void run(int64_t off, uint32_t v, bool aligned) const
+    {
+        if (NB == 1) pst1<true>(e, fb, off, v & 0xFFu);
+        else if (aligned) { if (NB == 2) pst2<true>(e, fb, off, v); else pst4<true>(e, fb, off, v); }
+        else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) pst1<true>(e, fb, off + i, (v >> (8 * i)) & 0xFFu);
+        }
+    }
+    template <int N> __device__ __forceinline__ void put(int row, int col, const uint32_t (&o)[N]) const
+    {
+        static_assert(N == 1 || N == 2 || N == 4, "a tile yields 1, 2 or 4 positions per row");
+        constexpr int NS = (N >> LHE) > 0 ? (N >> LHE) : 1;             // chroma samples among the N positions (N < hold_h: one or none)
+        uint32_t y = 0, cb = 0, cr = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) y |= (o[i] & 0xFFu) << (8 * i);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            cb |= ((o[i << LHE] >> 8) & 0xFFu) << (8 * i);
+            cr |= ((o[i << LHE] >> 16) & 0xFFu) << (8 * i);
+        }
+        // col is a multiple of N: a run is aligned iff its plane's rows are a multiple of its length apart
+        run<N>((int64_t)row * Wo + col, y, (Wo & (N - 1)) == 0);
+        if ((row & ((1 << LVE) - 1)) == 0 && (N >= (1 << LHE) || (col & ((1 << LHE) - 1)) == 0)) {
+            const int64_t k = (int64_t)(row >> LVE) * e.Wc + (col >> LHE);
+            const bool al = (e.Wc & (NS - 1)) == 0;
+            run<NS>(e.cb_off + k, cb, al);
+            run<NS>(e.cr_off + k, cr, al);
+        }
+    }
+    __device__ __forceinline__ void put_edge(int row, int col, uint32_t v) const
+    {
+        pst1<false>(e, fb, (int64_t)row * Wo + col, v & 0xFFu);
+        if ((col & ((1 << LHE) - 1)) == 0 && (row & ((1 << LVE) - 1)) == 0) {
+            const int64_t k = (int64_t)(row >> LVE) * e.Wc + (col >> LHE);
+            pst1<false>(e, fb, e.cb_off + k, (v >> 8) & 0xFFu);
+            pst1<false>(e, fb, e.cr_off + k, (v >> 16) & 0xFFu);
+        }
+    }
+};
+
+template <int ROUND, int F, int HH, int VV>
+__global__ void __launch_bounds__(256) k_planar_avg_tile(KArgs a, PExtra e)
+{
+    constexpr int HOLD_H = HH > F ? HH / F : 1, HOLD_V = VV > F ? VV / F : 1;        // csic_planar_layout under AVG
+    constexpr int LHE = HOLD_H == 4 ? 2 : HOLD_H == 2 ? 1 : 0, LVE = HOLD_V == 2 ? 1 : 0;
+    pin_args(a);
+    const PlanarSink<LHE, LVE> sink{e, planar_frame(e), a.Wo};
+    avg_kernel_body<ROUND, F_YCC, F, HH, VV, true, (F <= 2 ? 2 : 1)>(a, frame_in(a), sink);
+}
+
 // any factor, any shape: one output position per lane by the definition
 template <int ROUND>
 __global__ void __launch_bounds__(256) k_planar_avg_gen(KArgs a, PExtra e)
@@ -488,14 +552,25 @@ static void fill_extra(const csic_planar_layout &L, PExtra *e)
     magic_div((uint32_t)L.module_width, &e->mWm, &e->kWm);
 }
 
-// which forward kernel a plan takes: 0 = flat MODE 0, 1 = flat MODE 1, 2 = flat MODE 2, 3 = avg_f1, 4 = avg_gen
+// which forward kernel a plan takes: 0 = flat MODE 0, 1 = strided, 2 = flat MODE 2, 3 = avg_f1, 4 = avg_gen, 5 = flat MODE 1, 6 = avg_tile
 static int forward_kind(const csic_plan *pl, const csic_planar_layout &L)
 {
     const csic_params &p = plan_params(pl);
     const Geometry &g = plan_geometry(pl);
     const bool general = plan_variant(pl) == 9;                 // CSIC_TUNE_VARIANT 9: the general kernels (A/B, tests)
-    if (p.sampling == CSIC_SAMPLING_AVG)
-        return (!general && g.f == 1 && g.W % 4 == 0 && g.H % g.v == 0) ? 3 : 4;
+    if (p.sampling == CSIC_SAMPLING_AVG) {
+        const bool f1_whole = g.f == 1 && g.W % 4 == 0 && g.H % g.v == 0;
+        // factor 1 on frames of whole tiles: the dedicated kernel (Y bytes straight from the loaded pixels, no per-pixel write-back of
+        // the block averages) is 3 points ahead of k_avg's body there -- 8192x8192 4:2:0: 77.5 against 74.1 % of the roofline,
+        // profiles/r04_planar_avg_tile_ab.log; CSIC_TUNE_VARIANT 12 takes the tile body all the same (A/B, tests)
+        if (!general && f1_whole && (plan_variant(pl) != 12 || !plan_nontemporal(pl))) return 3;
+        if (!general && plan_nontemporal(pl)) {                  // k_avg's body wherever k_avg itself would run
+            LaunchDesc d;
+            bool tile = false;
+            if (planar_avg_geometry(pl, 1, &d, &tile) == CSIC_OK && tile) return 6;
+        }
+        return (!general && f1_whole) ? 3 : 4;
+    }
     if (general || L.module_width % 4 != 0) return 0;
     if (g.f == 1 && g.W % 4 == 0) return 2;
     return plan_variant(pl) == 10 ? 5 : 1;
@@ -516,6 +591,19 @@ static PlanarFn pick_forward(int kind, int he, int ve)
     }
 }
 
+template <int ROUND, int F>
+static PlanarFn pick_avg_tile_f(int h, int v)
+{
+    if (v == 1) return h == 1 ? k_planar_avg_tile<ROUND, F, 1, 1> : h == 2 ? k_planar_avg_tile<ROUND, F, 2, 1> : k_planar_avg_tile<ROUND, F, 4, 1>;
+    return h == 1 ? k_planar_avg_tile<ROUND, F, 1, 2> : h == 2 ? k_planar_avg_tile<ROUND, F, 2, 2> : k_planar_avg_tile<ROUND, F, 4, 2>;
+}
+template <int ROUND>
+static PlanarFn pick_avg_tile(int f, int h, int v)
+{
+    return f == 1 ? pick_avg_tile_f<ROUND, 1>(h, v) : f == 2 ? pick_avg_tile_f<ROUND, 2>(h, v)
+         : f == 4 ? pick_avg_tile_f<ROUND, 4>(h, v) : pick_avg_tile_f<ROUND, 8>(h, v);
+}
+
 void planar_kernel_name(const csic_plan *pl, char *buf, size_t len)
 {
     csic_planar_layout L;
@@ -528,6 +616,7 @@ void planar_kernel_name(const csic_plan *pl, char *buf, size_t len)
     case 5: snprintf(buf, len, "k_planar_flat<%s,f%d,h%d,v%d,%s>", rn, plan_geometry(pl).f, L.hold_h, L.hold_v, nt); break;
     case 2: snprintf(buf, len, "k_planar_flat<%s,f1x4,h%d,v%d,%s>", rn, L.hold_h, L.hold_v, nt); break;
     case 3: snprintf(buf, len, "k_planar_avg_f1<%s,h%d,v%d,%s>", rn, L.hold_h, L.hold_v, nt); break;
+    case 6: snprintf(buf, len, "k_planar_avg_tile<%s,f%d,h%d,v%d,nt>", rn, plan_geometry(pl).f, plan_geometry(pl).h, plan_geometry(pl).v); break;
     default: snprintf(buf, len, "k_planar_avg_gen<%s,h%d,v%d>", rn, L.hold_h, L.hold_v); break;
     }
 }
@@ -553,6 +642,7 @@ int planar_forward(const csic_plan *pl, const void *d_in, void *d_planar, int nf
     const bool floor_r = p.rounding == CSIC_ROUND_FLOOR_HW;
     PlanarFn fn = floor_r ? (nt ? pick_forward<R_FLOOR, true>(kind, L.hold_h, L.hold_v) : pick_forward<R_FLOOR, false>(kind, L.hold_h, L.hold_v))
                           : (nt ? pick_forward<R_TRUNC, true>(kind, L.hold_h, L.hold_v) : pick_forward<R_TRUNC, false>(kind, L.hold_h, L.hold_v));
+    if (kind == 6) fn = floor_r ? pick_avg_tile<R_FLOOR>(g.f, g.h, g.v) : pick_avg_tile<R_TRUNC>(g.f, g.h, g.v);
     for (int f0 = 0; f0 < nframes; f0 += 65535) {            // grid z limit
         const int nz = nframes - f0 < 65535 ? nframes - f0 : 65535;
         KArgs a;
@@ -562,7 +652,19 @@ int planar_forward(const csic_plan *pl, const void *d_in, void *d_planar, int nf
         fill_extra(L, &e);
         e.planar = static_cast<uint8_t *>(d_planar) + (int64_t)f0 * L.frame_bytes;
         dim3 grid, block;
-        if (kind == 1) {
+        if (kind == 6) {
+            // k_avg's own geometry (block shape, edge blocks, XCD rotation): prepare_common through the plan's packed twin
+            LaunchDesc d;
+            bool tile = false;
+            const int st = planar_avg_geometry(pl, nz, &d, &tile);
+            if (st != CSIC_OK) return st;
+            if (!tile) return set_error(CSIC_EHIP, "internal: the planar AVG tile kernel was selected for a plan k_avg does not take");
+            const uint32_t *in0 = a.in;
+            a = d.args;
+            a.in = in0;
+            grid = d.grid; block = d.block;
+            e.T = 256;
+        } else if (kind == 1) {
             // k_planar_strided: 4 positions per lane, T * 4 positions per block
             const int bt = plan_block_threads(pl);
             const int T = (bt == 64 || bt == 128 || bt == 256) ? bt : 256;

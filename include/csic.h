@@ -225,7 +225,8 @@ const char *csic_plan_kernel_name(const csic_plan *plan);
  *                       f = 1, 5 = k_dec instead of k_decflat on rows that do not tile into whole blocks / waves, 6 = k_decflat wherever it applies, 7 = the one-pixel-per-lane k_generic instead of k_flatgen,
  *                       8 = AVG: the tile kernel only for frames of whole tiles, as in rounds 1-3, 9 = planar: the general kernels instead of the fast paths,
  *                       10 = planar, factor >= 2: 4 consecutive positions per lane (k_planar_flat) instead of the transposing k_planar_strided,
- *                       11 = factor 1: k_f1x4 (rounds 1-3's kernel) instead of k_f1flat)
+ *                       11 = factor 1: k_f1x4 (rounds 1-3's kernel) instead of k_f1flat,
+ *                       12 = planar AVG at factor 1 on frames of whole tiles: k_avg's body with the planar sink instead of k_planar_avg_f1)
  *   CSIC_TUNE_FORCE_GENERIC : 1 = always use the one-thread-per-pixel generic kernel
  *   CSIC_TUNE_NONTEMPORAL   : 1 (default) = non-temporal loads/stores for the frame stream, 0 = cached
  *   CSIC_TUNE_NO_VECTOR     : 1 = never use the 16-byte-per-lane kernels

@@ -103,8 +103,30 @@ def test_planar_avg_random_shapes_vs_oracle(csic, oracle):
         bits = tuple(int(x) for x in rng.integers(1, 9, 3))
         f = int(rng.choice([1, 1, 1, 2, 4, 8]))
         argb = rng.integers(0, 1 << 32, W * H, dtype=np.uint32)
-        seen |= _check_one(csic, oracle, W, H, a, b, bits, f, CSQ, int(rng.integers(0, 2)), True, argb)
-    assert {"k_planar_avg_f1", "k_planar_avg_gen"} <= seen
+        seen |= _check_one(csic, oracle, W, H, a, b, bits, f, CSQ, int(rng.integers(0, 2)), True, argb, variants=(0, 9, 12))
+    assert {"k_planar_avg_f1", "k_planar_avg_gen", "k_planar_avg_gen*", "k_planar_avg_tile"} <= seen, seen
+
+
+@pytest.mark.parametrize("f", [1, 2, 4, 8])
+def test_planar_avg_tile_kernel_every_mode_and_ragged_shapes(csic, oracle, f):
+    """AVG through k_avg's tile body with the planar sink (k_planar_avg_tile), every factor: every chroma mode on
+    whole-tile frames, frames the tiles do not divide (edge blocks: cut columns, cut rows, both), output rows of odd width (two-byte
+    stores would start at odd bytes), rows wide enough for several blocks, and the one shape class where the chroma planes are
+    subsampled although the picture is decimated (4:1:1 at f = 2: hold_h = 2) -- planes and both reconstruct formats against the
+    oracle, default kernel and the one-position-per-lane kernel (variant 9)."""
+    rng = np.random.default_rng(9300 + f)
+    shapes = [(8 * f, 4 * f), (64, 32), (1030, 24), (1366, 16 + f), (8 * f + 3, 2 * f + 1), (250, 2 * f), (4 * f + 2, 8 * f + 5), (2056, 16)]
+    seen = set()
+    for (W, H) in shapes:
+        for (a, b) in MODES:
+            bits = tuple(int(x) for x in rng.integers(1, 9, 3))
+            argb = rng.integers(0, 1 << 32, W * H, dtype=np.uint32)
+            seen |= _check_one(csic, oracle, W, H, a, b, bits, f, CSQ, int(rng.integers(0, 2)), True, argb, variants=(0, 9, 12))
+    assert "k_planar_avg_tile" in seen and "k_planar_avg_gen*" in seen, seen
+    with _plan(csic, 64, 32, 1, 1, (8, 8, 8), 2, CSQ, avg=True) as pl:                 # 4:1:1 at f = 2: every second column is a sample
+        assert pl.kernel_name.startswith("k_planar_avg_tile") and pl.planar_layout.hold_h == 2, pl.kernel_name
+        pl.tune(csic._native.TUNE_NONTEMPORAL, 0)                                    # cached accesses: the general kernel serves them
+        assert pl.kernel_name.startswith("k_planar_avg_gen"), pl.kernel_name
 
 
 @pytest.mark.parametrize("W,H", [(256, 64), (1920, 16), (1000, 12), (4096, 8), (1028, 10), (36, 6)])

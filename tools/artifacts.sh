@@ -39,10 +39,13 @@ bench)
     $BN --config $c --frames-per-step 256 >> "$J" 2>> "$OUT/bench.err" || exit 1; done
   $BN --config avg_1366x768_sf4 --frames-per-step 256 --variant 8 >> "$J" 2>> "$OUT/bench.err" || exit 1   # A/B: rounds 1-3's rule (k_avg_generic for anything but whole tiles)
   $BN --config avg_1001_sf8 --frames-per-step 256 --variant 8 >> "$J" 2>> "$OUT/bench.err" || exit 1
+  # planar + AVG with a decimating factor: k_avg's tile body with the planar sink, and (variant 9) the one-position-per-lane kernel it replaced
+  $BN --config planar_cfg4_avg >> "$J" 2>> "$OUT/bench.err" || exit 1
+  $BN --config planar_cfg4_avg --variant 9 >> "$J" 2>> "$OUT/bench.err" || exit 1
   wc -l "$J"
   ;;
 profile)
-  for c in cfg4 cfg5 8k_444_f1 8k_420_f1 planar_8k_420_f1 planar_8k_420_f1_avg avg_8k_420_sf2; do
+  for c in cfg4 cfg5 8k_444_f1 8k_420_f1 planar_8k_420_f1 planar_8k_420_f1_avg planar_cfg4_avg avg_8k_420_sf2; do
     bash tools/profile.sh $TAG $c > "$OUT/profile_$c.log" 2>&1 || { tail -5 "$OUT/profile_$c.log"; exit 1; }
     echo "profiled $c"
   done

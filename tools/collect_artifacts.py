@@ -69,7 +69,7 @@ def main():
     if os.path.exists(sl):
         small_launch_md(sl, os.path.join(dst, f"{tag}_small_launch.md"), tag)
         copied.append("small_launch.md (rendered)")
-    for cfg in ("cfg4", "cfg5", "8k_444_f1", "8k_420_f1", "planar_8k_420_f1", "planar_8k_420_f1_avg", "avg_8k_420_sf2", "sq1000_csq", "sq1000_csq_kdec", "sq1000_scq", "sq1000_scq_kgeneric", "sq1024_scq", "sq1024_csq"):
+    for cfg in ("cfg4", "cfg5", "8k_444_f1", "8k_420_f1", "planar_8k_420_f1", "planar_8k_420_f1_avg", "planar_cfg4_avg", "avg_8k_420_sf2", "sq1000_csq", "sq1000_csq_kdec", "sq1000_scq", "sq1000_scq_kgeneric", "sq1024_scq", "sq1024_csq"):
         d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}" + ("" if cfg == "cfg4" else f"_{cfg}"))
         if os.path.isdir(d):
             subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), tag, cfg], stdout=subprocess.DEVNULL)

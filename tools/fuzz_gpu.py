@@ -65,12 +65,12 @@ while time.time() < t_end:
                 sys.exit(1)
         if rng.random() < 0.3 and not ycc_in:
             # the same parameters with planar output (CSIC_FMT_PLANAR): the planes against the oracle's planar form of its stream,
-            # and csic_reconstruct_device against the packed oracle output -- default, general (9) and 4-consecutive (10) kernels
+            # and csic_reconstruct_device against the packed oracle output -- default, general (9), 4-consecutive (10) kernels and the AVG tile body at factor 1 (12)
             lay_o, y_o, cb_o, cr_o = orc.planar(op_, frame, avg=avg)
             cpp = csic.make_c_params(W, H, a, b, *bits, f, op, rounding=rounding, out_format=2, sampling=1 if avg else 0)
             d_in = torch.from_numpy(frame.view(np.int32)).cuda()
             with csic.Plan(cpp, 0) as pp:
-                for variant in (0, 9, 10)[: 1 + int(rng.integers(0, 3))]:
+                for variant in (0, 9, 10, 12)[: 1 + int(rng.integers(0, 4))]:
                     pp.tune(N.TUNE_VARIANT, variant)
                     if rng.random() < 0.3:
                         pp.tune(N.TUNE_BLOCK_THREADS, int(rng.choice([0, 64, 128, 256])))

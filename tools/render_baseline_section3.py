@@ -78,6 +78,10 @@ New in round 4 (DESIGN.md §0):
   rule — so the "aligned" neighbours are themselves 9–13 × faster than they were: `profiles/r04_avg_edge_ab.log`, which also
   records the four placements of the edge work that were measured.) Headline AVG shape (row 5): {pct(5):.1f} % with packed 16-bit
   chroma sums (round 3: 74.5 %); traffic {r('avg_8k_420_sf2'):.4f} ×.
+* rows 30–31 — **planar AVG with a decimating factor**: `k_avg`'s tile body with a planar sink (`k_planar_avg_tile`; cfg 4's shape,
+  box-filtered, 3 bytes per output pixel): {pct(30):.1f} % = {us(30):.1f} µs per frame, against {pct(31):.1f} % = {us(31):.1f} µs for the one-position-per-lane kernel
+  every such plan took until late in round 4 (`CSIC_TUNE_VARIANT` 9, row 31); `csic_reconstruct_device` beside it {100 * rc(30)['roofline_frac']:.1f} %;
+  PMC traffic {r('planar_cfg4_avg'):.4f} ×.
 * rows 3–4, 7, 14 — **a faster factor-1 kernel**: `k_f1flat` (groups of 4 pixels over the flat frame, 4 groups per lane spaced by a
   one-wave block — the mapping the planar kernel found) replaces `k_f1x4`: 8192×8192 4:4:4 {pct(3):.1f} %, 4:2:0 + Q8 {pct(4):.1f} % (round 3:
   79.0 / 76.9 %), 128×128 at 4096 frames per launch {pct(14):.1f} % (77.7 %); A/B on one box over four chroma modes and twelve sizes:
