@@ -206,9 +206,11 @@ class FrameGraph:
             raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: need as many output as input frames (> 0)")
         if backend not in self.BACKENDS:
             raise N.IllegalArgumentException(N.EINVAL_SIZE, f"requirement failed: backend must be one of {sorted(self.BACKENDS)}")
+        # a planar plan's outputs are planar frame buffers (frame_bytes each, any 1- or 4-byte dtype; fused backend only)
+        out_bytes = plan.planar_layout.frame_bytes if plan.planar else 4 * plan.out_width * plan.out_height
         for t_in, t_out in zip(d_ins, d_outs):
-            if t_in.numel() != plan.width * plan.height or t_out.numel() != plan.out_width * plan.out_height \
-                    or t_in.element_size() != 4 or t_out.element_size() != 4 \
+            if t_in.numel() != plan.width * plan.height or t_out.numel() * t_out.element_size() != out_bytes \
+                    or t_in.element_size() != 4 or (t_out.element_size() != 4 and not plan.planar) \
                     or not t_in.is_contiguous() or not t_out.is_contiguous() \
                     or t_in.device.index != plan.device or t_out.device.index != plan.device:
                 raise N.IllegalArgumentException(N.EINVAL_SIZE, "requirement failed: frame tensor has the wrong size/layout/device")

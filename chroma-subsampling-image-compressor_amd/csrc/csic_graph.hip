@@ -391,6 +391,7 @@ struct csic_frame_graph {
     // FUSED backend: device-resident pointer tables + one launch descriptor per 65535 frames
     void *d_tables = nullptr;
     std::vector<LaunchDesc> fused;
+    std::vector<PlanarLaunchDesc> fused_planar;       // the same for a CSIC_FMT_PLANAR plan (d_out[k] = frame k's planar buffer)
     // DIRECT backend
     DirectEngine *eng = nullptr;
     void *d_kernarg = nullptr;
@@ -516,8 +517,20 @@ static int build_fused(csic_frame_graph *g, csic_plan *plan, const void *const *
     HIP_TRY(hipMemcpy(static_cast<uint8_t *>(g->d_tables) + bytes, d_out, bytes, hipMemcpyHostToDevice));
     const void *const *tin = static_cast<const void *const *>(g->d_tables);
     void *const *tout = reinterpret_cast<void *const *>(static_cast<uint8_t *>(g->d_tables) + bytes);
+    const bool planar = plan_params(plan).out_format == CSIC_FMT_PLANAR;
+    if (planar)
+        for (int k = 0; k < n; ++k)
+            if ((uintptr_t)d_out[k] & 255u)
+                return set_error(CSIC_EINVAL_SIZE, "frame %d: a planar frame buffer must be 256-byte aligned", k);
     for (int f0 = 0; f0 < n; f0 += 65535) {                       // grid z limit
         const int nz = (n - f0 < 65535) ? n - f0 : 65535;
+        if (planar) {
+            PlanarLaunchDesc d;
+            const int st = planar_prepare_table(plan, tin + f0, tout + f0, align_bits, nz, &d);
+            if (st != CSIC_OK) return st;
+            try { g->fused_planar.push_back(d); } catch (const std::bad_alloc &) { return set_error(CSIC_ENOMEM, "out of host memory"); }
+            continue;
+        }
         LaunchDesc d;
         const int st = prepare_launch_table(plan, tin + f0, tout + f0, align_bits, nz, &d);
         if (st != CSIC_OK) return st;
@@ -892,6 +905,9 @@ int csic_frame_graph_create_ex(csic_plan *plan, const void *const *d_in, void *c
     // stream-ordered way through them at every frame size (profiles/r02_small_launch.md); the per-frame-launch backends are
     // for callers that ask for per-frame launches by name.
     if (backend == CSIC_FRAME_GRAPH_AUTO) backend = CSIC_FRAME_GRAPH_FUSED;
+    if (plan_params(plan).out_format == CSIC_FMT_PLANAR && backend != CSIC_FRAME_GRAPH_FUSED)
+        return set_error(CSIC_EINVAL_FORMAT, "a planar plan's frame graph is one fused launch (CSIC_FRAME_GRAPH_AUTO / _FUSED); the per-frame-launch "
+                                              "backends take packed formats only");
     if (backend != CSIC_FRAME_GRAPH_HIP && backend != CSIC_FRAME_GRAPH_DIRECT && backend != CSIC_FRAME_GRAPH_FUSED)
         return set_error(CSIC_EINVAL_SIZE, "unknown frame-graph backend %d", backend);
     if (backend == CSIC_FRAME_GRAPH_FUSED) branches = 1;          // one launch: nothing to overlap with
@@ -942,6 +958,10 @@ int csic_frame_graph_launch(csic_frame_graph *g, void *hip_stream)
     if (g->backend == CSIC_FRAME_GRAPH_FUSED) {
         for (const LaunchDesc &d : g->fused) {
             const int st = enqueue(d, stream);
+            if (st != CSIC_OK) return st;
+        }
+        for (const PlanarLaunchDesc &d : g->fused_planar) {
+            const int st = planar_enqueue(d, stream);
             if (st != CSIC_OK) return st;
         }
         clear_error();

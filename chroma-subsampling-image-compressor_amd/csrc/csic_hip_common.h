@@ -79,7 +79,27 @@ bool plan_nontemporal(const csic_plan *pl);                  // CSIC_TUNE_NONTEM
 int plan_block_threads(const csic_plan *pl);                 // CSIC_TUNE_BLOCK_THREADS (0 = the library's choice)
 void fill_base_args(const Geometry &g, int32_t ip, int32_t op, KArgs *a);
 // csic_planar.hip: out_format = CSIC_FMT_PLANAR (forward: packed input -> planar frame buffers; name of the kernel a plan takes)
+// csic_planar.hip: the second kernel argument of the planar kernels, and a prepared planar launch (as LaunchDesc for the packed ones)
+struct PExtra {
+    uint8_t *planar;              // forward: destination frame buffers, frame_bytes apart; reconstruct: source
+    const uint64_t *planar_tab;   // forward, frame-table mode: device-resident table of the frames' planar buffers (else NULL)
+    uint32_t *packed;             // reconstruct: destination (n pixels per frame, back to back)
+    int64_t cb_off, cr_off, frame_bytes, n;
+    int32_t Wm, Wc, lhe, lve, replay_last;      // module width, samples per chroma row, log2 hold_h / hold_v
+    uint32_t mWm, kWm;                          // exact j / Wm (magic_div)
+    int32_t T;                                  // threads per block
+};
+struct PlanarLaunchDesc {
+    void (*fn)(KArgs, PExtra);
+    dim3 grid, block;
+    KArgs args;
+    PExtra extra;
+};
 int planar_forward(const csic_plan *pl, const void *d_in, void *d_planar, int nframes, hipStream_t stream);
+// `nframes` (<= 65535) frames in SEPARATE buffers named by device-resident pointer tables: resolves kernel + geometry (no device work)
+int planar_prepare_table(const csic_plan *pl, const void *const *d_in_tab, void *const *d_planar_tab, uintptr_t align_bits, int nframes,
+                         PlanarLaunchDesc *d);
+int planar_enqueue(const PlanarLaunchDesc &d, hipStream_t stream);
 void planar_kernel_name(const csic_plan *pl, char *buf, size_t len);
 int planar_avg_geometry(const csic_plan *pl, int nframes, LaunchDesc *d, bool *tile);   // k_avg's geometry for a planar AVG plan
 void plan_sizes(const csic_plan *pl, size_t *in_px, size_t *out_px);

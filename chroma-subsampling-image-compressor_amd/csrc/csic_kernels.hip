@@ -942,8 +942,8 @@ static int prepare_common(const csic_plan *pl, uintptr_t align_bits, int nframes
     if (nframes <= 0 || nframes > 65535)
         return set_error(CSIC_EINVAL_SIZE, "nframes per launch must be in 1..65535. Got %d", nframes);
     if (pl->p.out_format == CSIC_FMT_PLANAR)
-        return set_error(CSIC_EINVAL_FORMAT, "planar plans go through csic_process_device / csic_process_batch_device / csic_process_host "
-                                              "only (no row pitches, frame graphs, pipelines, file pools or csic_multi)");
+        return set_error(CSIC_EINVAL_FORMAT, "planar plans go through csic_process_device / csic_process_batch_device / csic_process_host, "
+                                              "csic_pipeline_* and fused frame graphs only (no row pitches, per-frame-launch graphs, file pools or csic_multi)");
     const Geometry &g = pl->g;
 
     Family fam = pl->fam;

@@ -42,15 +42,6 @@
 
 namespace csic {
 
-struct PExtra {
-    uint8_t *planar;              // forward: destination frame buffers; reconstruct: source
-    uint32_t *packed;             // reconstruct: destination (n pixels per frame, back to back)
-    int64_t cb_off, cr_off, frame_bytes, n;
-    int32_t Wm, Wc, lhe, lve, replay_last;      // module width, samples per chroma row, log2 hold_h / hold_v
-    uint32_t mWm, kWm;                          // exact j / Wm (magic_div)
-    int32_t T;                                  // threads per block
-};
-
 typedef uint8_t CSIC_GLOBAL *gbyte_t;
 typedef const uint8_t CSIC_GLOBAL *gcbyte_t;
 typedef unsigned short CSIC_GLOBAL *gshort_t;
@@ -85,7 +76,13 @@ template <bool NT> __device__ __forceinline__ uint32_t pld4(const PExtra &e, gcb
     return NT ? __builtin_nontemporal_load((gin_t)(base + off)) : *(gin_t)(base + off);
 }
 
-__device__ __forceinline__ gbyte_t planar_frame(const PExtra &e) { return (gbyte_t)(uintptr_t)e.planar + (int64_t)blockIdx.z * e.frame_bytes; }
+// base of the planar frame this block works on (grid z = frame): consecutive buffers, or -- frame-table mode -- whatever the
+// device-resident table names (read through the constant address space: one wave-uniform s_load, as frame_in / frame_out)
+__device__ __forceinline__ gbyte_t planar_frame(const PExtra &e)
+{
+    if (e.planar_tab) return (gbyte_t)((const uint64_t CSIC_CONSTANT *)(uintptr_t)e.planar_tab)[blockIdx.z];
+    return (gbyte_t)(uintptr_t)e.planar + (int64_t)blockIdx.z * e.frame_bytes;
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward, HOLD_DECIMATE
@@ -628,11 +625,9 @@ static int launch_pk(PlanarFn fn, dim3 grid, dim3 block, KArgs a, PExtra e, hipS
     return CSIC_OK;
 }
 
-int planar_forward(const csic_plan *pl, const void *d_in, void *d_planar, int nframes, hipStream_t stream)
+// kernel, grid, block and both argument blocks of one forward launch over nz <= 65535 frames; the frame pointers stay unset
+static int planar_resolve(const csic_plan *pl, int nz, PlanarLaunchDesc *d)
 {
-    if (!d_in || !d_planar) return set_error(CSIC_EINVAL_NULL, "device buffer is NULL");
-    if (((uintptr_t)d_planar & 255u) || ((uintptr_t)d_in & 3u))
-        return set_error(CSIC_EINVAL_SIZE, "a planar frame buffer must be 256-byte aligned (and the input 4-byte aligned)");
     const csic_params &p = plan_params(pl);
     const Geometry &g = plan_geometry(pl);
     csic_planar_layout L;
@@ -643,62 +638,88 @@ int planar_forward(const csic_plan *pl, const void *d_in, void *d_planar, int nf
     PlanarFn fn = floor_r ? (nt ? pick_forward<R_FLOOR, true>(kind, L.hold_h, L.hold_v) : pick_forward<R_FLOOR, false>(kind, L.hold_h, L.hold_v))
                           : (nt ? pick_forward<R_TRUNC, true>(kind, L.hold_h, L.hold_v) : pick_forward<R_TRUNC, false>(kind, L.hold_h, L.hold_v));
     if (kind == 6) fn = floor_r ? pick_avg_tile<R_FLOOR>(g.f, g.h, g.v) : pick_avg_tile<R_TRUNC>(g.f, g.h, g.v);
+    KArgs &a = d->args;
+    PExtra &e = d->extra;
+    fill_base_args(g, g.W, g.Wo, &a);
+    fill_extra(L, &e);
+    dim3 grid, block;
+    if (kind == 6) {
+        // k_avg's own geometry (block shape, edge blocks, XCD rotation): prepare_common through the plan's packed twin
+        LaunchDesc ld;
+        bool tile = false;
+        const int st = planar_avg_geometry(pl, nz, &ld, &tile);
+        if (st != CSIC_OK) return st;
+        if (!tile) return set_error(CSIC_EHIP, "internal: the planar AVG tile kernel was selected for a plan k_avg does not take");
+        a = ld.args;
+        grid = ld.grid; block = ld.block;
+        e.T = 256;
+    } else if (kind == 1) {
+        // k_planar_strided: 4 positions per lane, T * 4 positions per block
+        const int bt = plan_block_threads(pl);
+        const int T = (bt == 64 || bt == 128 || bt == 256) ? bt : 256;
+        e.T = T;
+        block = dim3((unsigned)T, 1, 1);
+        grid = dim3((unsigned)((e.n + (int64_t)T * 4 - 1) / ((int64_t)T * 4)), 1, (unsigned)nz);
+        a.bdx = T; a.bdy = 1; a.row_step = 1;
+    } else if (kind <= 2 || kind == 5) {
+        const int64_t ngroups = (e.n + 3) / 4;
+        const int bt = plan_block_threads(pl);
+        // one-wave blocks for the 16-byte-load kernel: a wave's four loads then cover 4 KiB of consecutive pixels
+        // (8192x8192 4:2:0: 71.7 % of the roofline with 256-thread blocks, 77.6 % with 64; profiles/r04_planar_bt.log)
+        const int T = (bt == 64 || bt == 128 || bt == 256) ? bt : (kind == 2 ? 64 : 256);
+        e.T = T;
+        block = dim3((unsigned)T, 1, 1);
+        grid = dim3((unsigned)((ngroups + (int64_t)T * PLANAR_K - 1) / ((int64_t)T * PLANAR_K)), 1, (unsigned)nz);
+        a.bdx = T; a.bdy = 1; a.row_step = 1;
+    } else {
+        // row-tiled kernels: lanes along x (tiles of 4 pixels for avg_f1 with 2 tiles per lane, output pixels for avg_gen)
+        const int lanes_x = kind == 3 ? (g.W / 4 + 1) / 2 : g.Wo;
+        const int rows = kind == 3 ? g.H / g.v : g.Ho;
+        int bx = 1;
+        while (bx < lanes_x && bx < 256) bx <<= 1;
+        const int by = 256 / bx;
+        unsigned gy = (unsigned)((rows + by - 1) / by);
+        if (gy > 65535u) gy = 65535u;
+        block = dim3(bx, by, 1);
+        grid = dim3((unsigned)((lanes_x + bx - 1) / bx), gy, (unsigned)nz);
+        a.bdx = bx; a.bdy = by; a.row_step = (int32_t)gy * by;
+        e.T = 256;
+    }
+    d->fn = fn; d->grid = grid; d->block = block;
+    return CSIC_OK;
+}
+
+int planar_enqueue(const PlanarLaunchDesc &d, hipStream_t stream) { return launch_pk(d.fn, d.grid, d.block, d.args, d.extra, stream); }
+
+int planar_forward(const csic_plan *pl, const void *d_in, void *d_planar, int nframes, hipStream_t stream)
+{
+    if (!d_in || !d_planar) return set_error(CSIC_EINVAL_NULL, "device buffer is NULL");
+    if (((uintptr_t)d_planar & 255u) || ((uintptr_t)d_in & 3u))
+        return set_error(CSIC_EINVAL_SIZE, "a planar frame buffer must be 256-byte aligned (and the input 4-byte aligned)");
     for (int f0 = 0; f0 < nframes; f0 += 65535) {            // grid z limit
         const int nz = nframes - f0 < 65535 ? nframes - f0 : 65535;
-        KArgs a;
-        fill_base_args(g, g.W, g.Wo, &a);
-        a.in = static_cast<const uint32_t *>(d_in) + (int64_t)f0 * a.in_frame_px;
-        PExtra e;
-        fill_extra(L, &e);
-        e.planar = static_cast<uint8_t *>(d_planar) + (int64_t)f0 * L.frame_bytes;
-        dim3 grid, block;
-        if (kind == 6) {
-            // k_avg's own geometry (block shape, edge blocks, XCD rotation): prepare_common through the plan's packed twin
-            LaunchDesc d;
-            bool tile = false;
-            const int st = planar_avg_geometry(pl, nz, &d, &tile);
-            if (st != CSIC_OK) return st;
-            if (!tile) return set_error(CSIC_EHIP, "internal: the planar AVG tile kernel was selected for a plan k_avg does not take");
-            const uint32_t *in0 = a.in;
-            a = d.args;
-            a.in = in0;
-            grid = d.grid; block = d.block;
-            e.T = 256;
-        } else if (kind == 1) {
-            // k_planar_strided: 4 positions per lane, T * 4 positions per block
-            const int bt = plan_block_threads(pl);
-            const int T = (bt == 64 || bt == 128 || bt == 256) ? bt : 256;
-            e.T = T;
-            block = dim3((unsigned)T, 1, 1);
-            grid = dim3((unsigned)((e.n + (int64_t)T * 4 - 1) / ((int64_t)T * 4)), 1, (unsigned)nz);
-            a.bdx = T; a.bdy = 1; a.row_step = 1;
-        } else if (kind <= 2 || kind == 5) {
-            const int64_t ngroups = (e.n + 3) / 4;
-            const int bt = plan_block_threads(pl);
-            // one-wave blocks for the 16-byte-load kernel: a wave's four loads then cover 4 KiB of consecutive pixels
-            // (8192x8192 4:2:0: 71.7 % of the roofline with 256-thread blocks, 77.6 % with 64; profiles/r04_planar_bt.log)
-            const int T = (bt == 64 || bt == 128 || bt == 256) ? bt : (kind == 2 ? 64 : 256);
-            e.T = T;
-            block = dim3((unsigned)T, 1, 1);
-            grid = dim3((unsigned)((ngroups + (int64_t)T * PLANAR_K - 1) / ((int64_t)T * PLANAR_K)), 1, (unsigned)nz);
-            a.bdx = T; a.bdy = 1; a.row_step = 1;
-        } else {
-            // row-tiled kernels: lanes along x (tiles of 4 pixels for avg_f1 with 2 tiles per lane, output pixels for avg_gen)
-            const int lanes_x = kind == 3 ? (g.W / 4 + 1) / 2 : g.Wo;
-            const int rows = kind == 3 ? g.H / g.v : g.Ho;
-            int bx = 1;
-            while (bx < lanes_x && bx < 256) bx <<= 1;
-            const int by = 256 / bx;
-            unsigned gy = (unsigned)((rows + by - 1) / by);
-            if (gy > 65535u) gy = 65535u;
-            block = dim3(bx, by, 1);
-            grid = dim3((unsigned)((lanes_x + bx - 1) / bx), gy, (unsigned)nz);
-            a.bdx = bx; a.bdy = by; a.row_step = (int32_t)gy * by;
-            e.T = 256;
-        }
-        const int st = launch_pk(fn, grid, block, a, e, stream);
+        PlanarLaunchDesc d;
+        int st = planar_resolve(pl, nz, &d);
+        if (st != CSIC_OK) return st;
+        d.args.in = static_cast<const uint32_t *>(d_in) + (int64_t)f0 * d.args.in_frame_px;
+        d.extra.planar = static_cast<uint8_t *>(d_planar) + (int64_t)f0 * d.extra.frame_bytes;
+        st = planar_enqueue(d, stream);
         if (st != CSIC_OK) return st;
     }
+    return CSIC_OK;
+}
+
+int planar_prepare_table(const csic_plan *pl, const void *const *d_in_tab, void *const *d_planar_tab, uintptr_t align_bits, int nframes,
+                         PlanarLaunchDesc *d)
+{
+    if (!pl) return set_error(CSIC_EINVAL_NULL, "plan is NULL");
+    if (!d_in_tab || !d_planar_tab) return set_error(CSIC_EINVAL_NULL, "frame table is NULL");
+    if (nframes <= 0 || nframes > 65535) return set_error(CSIC_EINVAL_SIZE, "nframes per launch must be in 1..65535. Got %d", nframes);
+    if (align_bits & 3u) return set_error(CSIC_EINVAL_SIZE, "frame buffers must be 4-byte aligned");
+    const int st = planar_resolve(pl, nframes, d);
+    if (st != CSIC_OK) return st;
+    d->args.in_tab = reinterpret_cast<const uint32_t *const *>(d_in_tab);
+    d->extra.planar_tab = reinterpret_cast<const uint64_t *>(d_planar_tab);
     return CSIC_OK;
 }
 

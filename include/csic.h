@@ -261,8 +261,9 @@ int  csic_process_pitched_device(csic_plan *plan, const void *d_in, int32_t in_p
 
 /* With out_format = CSIC_FMT_PLANAR, d_out of csic_process_device / csic_process_batch_device is a planar frame buffer of
  * csic_planar_layout.frame_bytes bytes per frame (256-byte aligned); csic_process_host and csic_pipeline_* hand the same
- * buffer to the host.  Row pitches, frame graphs, the file pools and csic_multi_* take packed formats only
- * (CSIC_EINVAL_FORMAT otherwise).
+ * buffer to the host, and a frame graph of a planar plan (CSIC_FRAME_GRAPH_AUTO / _FUSED: one launch over the frames'
+ * buffers) takes d_out[k] = frame k's planar buffer.  Row pitches, the per-frame-launch graph backends (_HIP, _DIRECT), the
+ * file pools and csic_multi_* take packed formats only (CSIC_EINVAL_FORMAT otherwise).
  *
  * csic_reconstruct_device: `nframes` planar frames of `plan`'s parameters (the plan may have any out_format: only its
  * parameters matter) -> packed pixels, out_format = CSIC_FMT_ARGB8888 or CSIC_FMT_YCBCR888X, out_width * out_height per

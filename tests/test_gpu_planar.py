@@ -222,9 +222,13 @@ def test_planar_is_refused_where_packed_pixels_are_expected(csic, oracle):
     with _plan(csic, 64, 16, 2, 0, (8, 8, 8), 1, CSQ) as pl:
         d_in = torch.zeros(64 * 16, dtype=torch.int32, device="cuda:0")
         d_out = torch.zeros(pl.planar_layout.frame_bytes, dtype=torch.uint8, device="cuda:0")
-        with pytest.raises(csic.IllegalArgumentException, match="planar"):
-            pin, pout, h = (C.c_void_p * 1)(C.c_void_p(d_in.data_ptr())), (C.c_void_p * 1)(C.c_void_p(d_out.data_ptr())), C.c_void_p()
-            N.check(lib.csic_frame_graph_create_ex(pl._h, pin, pout, 1, 0, N.FRAME_GRAPH_FUSED, C.byref(h)))
+        pin, pout, h = (C.c_void_p * 1)(C.c_void_p(d_in.data_ptr())), (C.c_void_p * 1)(C.c_void_p(d_out.data_ptr())), C.c_void_p()
+        for backend in (N.FRAME_GRAPH_HIP, N.FRAME_GRAPH_DIRECT):                     # per-frame-launch graphs: packed formats only
+            with pytest.raises(csic.IllegalArgumentException, match="planar"):
+                N.check(lib.csic_frame_graph_create_ex(pl._h, pin, pout, 1, 0, backend, C.byref(h)))
+        with pytest.raises(csic.IllegalArgumentException, match="256-byte"):          # a fused graph takes them, aligned
+            pbad = (C.c_void_p * 1)(C.c_void_p(d_out.data_ptr() + 16))
+            N.check(lib.csic_frame_graph_create_ex(pl._h, pin, pbad, 1, 0, N.FRAME_GRAPH_FUSED, C.byref(h)))
         with pytest.raises(csic.IllegalArgumentException, match="pitch"):
             N.check(lib.csic_process_pitched_device(pl._h, C.c_void_p(d_in.data_ptr()), 64, C.c_void_p(d_out.data_ptr()), 64, 1, None))
         with pytest.raises(csic.IllegalArgumentException):          # a misaligned planar buffer
@@ -254,6 +258,45 @@ def test_planar_through_the_host_frame_pipeline(csic, oracle, zero_copy):
                 _, y_o, cb_o, cr_o = oracle.planar(op_, fr.reshape(-1), avg=avg)
                 y, cb, cr = pl.split_planar(got)
                 assert np.array_equal(y, y_o) and np.array_equal(cb, cb_o) and np.array_equal(cr, cr_o), (W, H, a, b, f, order, avg)
+
+
+def test_planar_through_a_fused_frame_graph(csic, oracle):
+    """csic_frame_graph_* with a CSIC_FMT_PLANAR plan: frames in SEPARATE buffers, one launch over a device-resident pointer table
+    (AUTO resolves to FUSED), d_out[k] = frame k's planar buffer -- every forward kernel family, planes against the oracle's planar
+    form frame by frame, a canary in the bytes the format does not own, replayed twice."""
+    import torch
+    rng = np.random.default_rng(88)
+    cases = ((64, 16, 2, 0, 1, CSQ, False, "k_planar_flat"), (250, 37, 2, 0, 2, CSQ, False, "k_planar_flat"), (256, 24, 2, 0, 2, CSQ, False, "k_planar_strided"),
+             (96, 20, 2, 2, 2, (1, 3, 2), False, "k_planar_strided"), (128, 32, 2, 0, 1, CSQ, True, "k_planar_avg_f1"), (1366, 18, 2, 0, 2, CSQ, True, "k_planar_avg_tile"),
+             (3, 5, 2, 0, 4, CSQ, True, "k_planar_avg_gen"))
+    for (W, H, a, b, f, order, avg, family) in cases:
+        nf = 5
+        frames = [rng.integers(0, 1 << 32, W * H, dtype=np.uint32) for _ in range(nf)]
+        op_ = oracle.OracleParams(width=W, height=H, chroma_a=a, chroma_b=b, y_bits=6, cb_bits=5, cr_bits=7, factor=f, op=order, rounding=0)
+        cp = csic.make_c_params(W, H, a, b, 6, 5, 7, f, order, out_format=csic.PixelFormat.PLANAR, sampling=1 if avg else 0)
+        with csic.Plan(cp, 0) as pl:
+            assert pl.kernel_name.startswith(family), (pl.kernel_name, family)
+            lay = pl.planar_layout
+            d_ins = [torch.from_numpy(fr.view(np.int32)).cuda() for fr in frames]
+            d_outs = [torch.full((lay.frame_bytes,), 0xA7, dtype=torch.uint8, device="cuda:0") for _ in range(nf)]
+            torch.cuda.synchronize()
+            with csic.FrameGraph(pl, d_ins, d_outs) as g:
+                assert g.backend == "fused"
+                for _ in range(2):
+                    g.launch()
+                torch.cuda.synchronize()
+            owned = np.zeros(lay.frame_bytes, dtype=bool)
+            owned[lay.y_offset:lay.y_offset + lay.y_width * lay.y_height] = True
+            owned[lay.cb_offset:lay.cb_offset + lay.chroma_samples] = True
+            owned[lay.cr_offset:lay.cr_offset + lay.chroma_samples] = True
+            for fr, out in zip(frames, d_outs):
+                host = out.cpu().numpy()
+                _, y_o, cb_o, cr_o = oracle.planar(op_, fr, avg=avg)
+                y, cb, cr = pl.split_planar(host)
+                assert np.array_equal(y, y_o) and np.array_equal(cb, cb_o) and np.array_equal(cr, cr_o), (W, H, a, b, f, order, avg)
+                assert (host[~owned] == 0xA7).all(), (W, H, f, avg)
+            with pytest.raises(csic.IllegalArgumentException):
+                csic.FrameGraph(pl, d_ins, d_outs, backend="hip")
 
 
 def test_preferred_pitch_rule(csic):

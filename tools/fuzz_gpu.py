@@ -84,6 +84,25 @@ while time.time() < t_end:
                               f"rounding={rounding} fmt={fmt} avg={avg} y={np.array_equal(y, y_o)} cb={np.array_equal(cb, cb_o)} cr={np.array_equal(cr, cr_o)} "
                               f"recon={np.array_equal(back, want)}")
                         sys.exit(1)
+                if rng.random() < 0.3:
+                    # ... and 1-4 frames in separate buffers through a fused frame graph of the planar plan
+                    pp.tune(N.TUNE_VARIANT, 0)
+                    nf = int(rng.integers(1, 5))
+                    frs = [frame] + [rng.integers(0, 1 << 32, W * H, dtype=np.uint32) for _ in range(nf - 1)]
+                    d_is = [torch.from_numpy(fr.view(np.int32)).cuda() for fr in frs]
+                    d_os = [torch.zeros(pp.planar_layout.frame_bytes, dtype=torch.uint8, device="cuda:0") for _ in range(nf)]
+                    torch.cuda.synchronize()
+                    with csic.FrameGraph(pp, d_is, d_os) as g:
+                        g.launch()
+                        torch.cuda.synchronize()
+                    families["graph:fused:planar"] = families.get("graph:fused:planar", 0) + 1
+                    for fr, d_o in zip(frs, d_os):
+                        _, y_w, cb_w, cr_w = orc.planar(op_, fr, avg=avg)
+                        y, cb, cr = pp.split_planar(d_o.cpu().numpy())
+                        if not (np.array_equal(y, y_w) and np.array_equal(cb, cb_w) and np.array_equal(cr, cr_w)):
+                            print(f"MISMATCH (planar, fused frame graph of {nf}) seed={seed} case={n} {pp.kernel_name} W={W} H={H} a={a} b={b} bits={bits} f={f} "
+                                  f"op={op} rounding={rounding} avg={avg}")
+                            sys.exit(1)
         if rng.random() < 0.34 and not ycc_in:
             # the same frame, 1-5 copies with different contents, through a pre-recorded frame graph
             for knob in (N.TUNE_NONTEMPORAL, N.TUNE_NO_VECTOR, N.TUNE_VARIANT, N.TUNE_FORCE_GENERIC):
