@@ -456,7 +456,7 @@ class Workload:
             # BASELINE.json configs[4] literally: pre-recorded per-frame launches, one graph per ring slot
             for k in range(nring):
                 fin = [self.ins[k][j * self.in_px:(j + 1) * self.in_px] for j in range(fps)]
-                fout = [self.outs[k][j * self.out_px:(j + 1) * self.out_px] for j in range(fps)]
+                fout = [self.outs[k][j * self.out_words:(j + 1) * self.out_words] for j in range(fps)]     # (planar: frame_bytes / 4 words)
                 self.graphs.append(csic.FrameGraph(self.plan, fin, fout, branches=branches, backend=backend))
             self.launch_desc = describe(self.graphs[0], f"{fps} per-frame launches per step")
 
