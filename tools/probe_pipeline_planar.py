@@ -32,4 +32,4 @@ for f in (1, 2):
                 run(n)
                 dt = time.perf_counter() - t0
             print(json.dumps({"f": f, "out": fmt_name, "mode": "zero_copy" if zero_copy else "staged", "frames_per_s": round(n / dt, 1),
-                              "in_Mpixel_per_s": round(n * W * H / dt / 1e6, 1), "kernel": None}), flush=True)
+                              "in_Mpixel_per_s": round(n * W * H / dt / 1e6, 1)}), flush=True)
