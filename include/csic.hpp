@@ -10,8 +10,10 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "csic.h"
@@ -39,7 +41,7 @@ inline int check(int status)
 
 enum class ProcessingStep : int32_t { NoOp = 0, SpatialSampling = 1, ColorQuantization = 2, ChromaSubsampling = 3 };
 enum class Rounding : int32_t { FLOOR_HW = CSIC_ROUND_FLOOR_HW, TRUNC_SW = CSIC_ROUND_TRUNC_SW };
-enum class PixelFormat : int32_t { ARGB8888 = CSIC_FMT_ARGB8888, YCBCR888X = CSIC_FMT_YCBCR888X };
+enum class PixelFormat : int32_t { ARGB8888 = CSIC_FMT_ARGB8888, YCBCR888X = CSIC_FMT_YCBCR888X, PLANAR = CSIC_FMT_PLANAR };
 
 struct ImageProcessorParams {
     int width, height, factor, chromaParamA, chromaParamB;
@@ -87,6 +89,16 @@ struct ImageProcessorModel {
     }
 };
 
+// One frame in the subsampled planar format (CSIC_FMT_PLANAR, csic.h: csic_planar_layout): the frame buffer as the device wrote
+// it, and views of its three planes -- Y: y_width x y_height bytes, Cb / Cr: chroma_samples bytes each in sample order.
+struct PlanarFrame {
+    csic_planar_layout layout{};
+    std::vector<uint8_t> bytes;                                   // layout.frame_bytes long
+    const uint8_t *y() const { return bytes.data() + layout.y_offset; }
+    const uint8_t *cb() const { return bytes.data() + layout.cb_offset; }
+    const uint8_t *cr() const { return bytes.data() + layout.cr_offset; }
+};
+
 class ImageCompressorTop {
 public:
     ImageCompressorTop(int width, int height, int chroma_param_a_config, int chroma_param_b_config,
@@ -108,8 +120,7 @@ public:
     ImageCompressorTop &operator=(const ImageCompressorTop &) = delete;
     virtual ~ImageCompressorTop()
     {
-        csic_plan_destroy(plan_[0]);
-        csic_plan_destroy(plan_[1]);
+        for (csic_plan *pl : plan_) csic_plan_destroy(pl);
     }
 
     int outWidth() const { return out_w_; }
@@ -124,6 +135,37 @@ public:
     void processDevice(const void *d_in, void *d_out, void *hip_stream, PixelFormat f = PixelFormat::ARGB8888)
     {
         check(csic_process_device(plan(f), d_in, d_out, hip_stream));
+    }
+    // The subsampled wire format the reference's README describes and its code never builds (README.md:35-46,
+    // ChromaSubsampler.scala:57-65): planarLayout() needs no GPU; processPlanar() moves one host frame; on the device,
+    // processDevice(..., PixelFormat::PLANAR) writes layout.frame_bytes bytes per frame (256-byte aligned) and
+    // reconstructDevice() turns planar frames back into the packed stream -- reconstruct(planar(x)) == process(x).
+    csic_planar_layout planarLayout() const
+    {
+        csic_planar_layout lay;
+        check(csic_planar_layout_of(&params_, &lay));
+        return lay;
+    }
+    PlanarFrame processPlanar(const std::vector<uint32_t> &argb)
+    {
+        PlanarFrame fr;
+        fr.layout = planarLayout();
+        std::vector<uint32_t> words((size_t)(fr.layout.frame_bytes / 4));
+        check(csic_process_host(plan(PixelFormat::PLANAR), argb.data(), argb.size(), words.data(), words.size()));
+        fr.bytes.resize((size_t)fr.layout.frame_bytes);
+        std::memcpy(fr.bytes.data(), words.data(), fr.bytes.size());
+        return fr;
+    }
+    void reconstructDevice(const void *d_planar, void *d_out, int nframes, void *hip_stream, PixelFormat f = PixelFormat::ARGB8888)
+    {
+        check(csic_reconstruct_device(plan(PixelFormat::PLANAR), d_planar, d_out, nframes, (int32_t)f, hip_stream));
+    }
+    // what row pitch (pixels, input / output) a caller that owns its surfaces should allocate for csic_process_pitched_device
+    std::pair<int, int> preferredPitch(PixelFormat f = PixelFormat::ARGB8888)
+    {
+        int32_t ip = 0, op = 0;
+        check(csic_plan_preferred_pitch(plan(f), &ip, &op));
+        return {ip, op};
     }
     const char *kernelName(PixelFormat f = PixelFormat::ARGB8888) { return csic_plan_kernel_name(plan(f)); }
     // the plan behind process(): what FrameGraph records launches of (owned by this object)
@@ -147,7 +189,7 @@ private:
         return out;
     }
     csic_params params_{};
-    csic_plan *plan_[2] = {nullptr, nullptr};
+    csic_plan *plan_[3] = {nullptr, nullptr, nullptr};     // one per PixelFormat
     int32_t out_w_ = 0, out_h_ = 0;
     int device_;
 };

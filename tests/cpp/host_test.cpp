@@ -34,6 +34,14 @@ static void cpu_checks()
     try { ImageProcessorParams(16, 16, 3, 4, 4); } catch (const IllegalArgumentException &e) {
         EXPECT(std::strstr(e.what(), "requirement failed: factor must be 1, 2, 4, or 8") != nullptr);
     }
+    // the planar layout is host arithmetic: 64x16 4:2:0 at factor 1 stores 1024 Y bytes and 2 x 256 chroma samples
+    {
+        ImageCompressorTop p(64, 16, 2, 0, 8, 8, 8, 1, PS::ChromaSubsampling, PS::SpatialSampling, PS::ColorQuantization);
+        const csic_planar_layout lay = p.planarLayout();
+        EXPECT(lay.y_width == 64 && lay.y_height == 16 && lay.hold_h == 2 && lay.hold_v == 2 && lay.replay_last == 1);
+        EXPECT(lay.chroma_width == 32 && lay.chroma_height == 8 && lay.chroma_samples == 256 && lay.payload_bytes == 1536);
+        EXPECT(lay.cb_offset % 256 == 0 && lay.cr_offset % 256 == 0 && lay.frame_bytes % 256 == 0 && lay.frame_bytes >= lay.payload_bytes);
+    }
 }
 
 // The device guard every csic_* entry point opens (csrc/csic_device_guard.h), driven by a fake runtime: it must
@@ -101,6 +109,31 @@ static void gpu_checks()
         ImageCompressorTop t(1, 1, 4, 4, 3, 3, 2, 1, PS::ColorQuantization, PS::SpatialSampling, PS::ChromaSubsampling);
         const auto o = t.processYCbCr({argb(235, 235, 235)});
         EXPECT(o[0] == ycc(224, 128, 128));
+    }
+    // planar output against the packed YCbCr stream of the same object: the Y plane is the stream's Y bytes, the chroma planes
+    // are its Cb / Cr at the sample points (4:2:0, factor 1: even rows, even columns); the preferred pitch is the packed one
+    {
+        const int W = 64, H = 16;
+        std::vector<uint32_t> img((size_t)W * H);
+        uint32_t x = 12345u;
+        for (auto &px : img) { x = x * 1664525u + 1013904223u; px = 0xFF000000u | (x >> 8); }
+        ImageCompressorTop t(W, H, 2, 0, 7, 6, 5, 1, PS::ChromaSubsampling, PS::SpatialSampling, PS::ColorQuantization);
+        const auto packed = t.processYCbCr(img);
+        const PlanarFrame fr = t.processPlanar(img);
+        EXPECT((int64_t)fr.bytes.size() == fr.layout.frame_bytes && fr.layout.chroma_samples == (W / 2) * (H / 2));
+        bool ok = true;
+        for (int r = 0; r < H; ++r)
+            for (int c = 0; c < W; ++c) {
+                ok = ok && fr.y()[r * W + c] == (packed[r * W + c] & 0xFF);
+                if (r % 2 == 0 && c % 2 == 0) {
+                    const int k = (r / 2) * fr.layout.chroma_width + c / 2;
+                    ok = ok && fr.cb()[k] == ((packed[r * W + c] >> 8) & 0xFF) && fr.cr()[k] == ((packed[r * W + c] >> 16) & 0xFF);
+                }
+            }
+        EXPECT(ok);
+        EXPECT(std::strncmp(t.kernelName(PixelFormat::PLANAR), "k_planar_flat", 13) == 0);
+        const auto pitch = t.preferredPitch();
+        EXPECT(pitch.first == W && pitch.second == W);
     }
     // wrong buffer size is an IllegalArgumentException, bad device a RuntimeError
     {
