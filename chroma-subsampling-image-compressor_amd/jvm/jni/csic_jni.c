@@ -36,7 +36,8 @@
 typedef struct csic_jni_handle {
     csic_plan *plan;
     csic_pipeline *pipe;        /* created by the first process(); NULL again after a failed frame */
-    size_t in_px, out_px;
+    size_t in_px, out_px;       /* out_px: 4-byte words per output frame (a planar plan: frame_bytes / 4) */
+    int planar;                 /* the plan's out_format is CSIC_FMT_PLANAR */
 } csic_jni_handle;
 
 static int is_require(int status) { return status <= CSIC_EINVAL_NULL && status >= CSIC_EINVAL_SIZE; }
@@ -99,6 +100,13 @@ JNIEXPORT jlong JNICALL Java_jpeg_NativeBackend_00024_planCreate(JNIEnv *env, jo
     if (st != CSIC_OK) { free(h); throw_for(env, st); return 0; }
     h->in_px = (size_t)p.width * (size_t)p.height;
     h->out_px = (size_t)wo * (size_t)ho;
+    if (p.out_format == CSIC_FMT_PLANAR) {         /* the pipeline hands back the planar frame buffer (csic.h) */
+        csic_planar_layout lay;
+        st = csic_planar_layout_of(&p, &lay);
+        if (st != CSIC_OK) { csic_plan_destroy(h->plan); free(h); throw_for(env, st); return 0; }
+        h->out_px = (size_t)(lay.frame_bytes / 4);
+        h->planar = 1;
+    }
     return (jlong)(intptr_t)h;
 }
 
@@ -126,7 +134,31 @@ JNIEXPORT jintArray JNICALL Java_jpeg_NativeBackend_00024_outDims(JNIEnv *env, j
     return r;
 }
 
-/* in: ARGB ints (Java int == CSIC_FMT_ARGB8888); out: ARGB or Y|Cb<<8|Cr<<16 per the plan's out_format */
+/* One frame through the handle's depth-1 pipeline: Java int[] -> pinned input slot -> fused kernel -> pinned output slot.
+ * Returns the pinned output (valid until the next frame) or NULL with an exception pending. */
+static const uint32_t *round_trip(JNIEnv *env, csic_jni_handle *h, jintArray jin, jsize nin)
+{
+    int st = CSIC_OK;
+    if (!h->pipe) st = csic_pipeline_create(h->plan, 1, &h->pipe);
+    uint32_t *pin = NULL;
+    const uint32_t *pout = NULL;
+    if (st == CSIC_OK) st = csic_pipeline_acquire_input(h->pipe, &pin);
+    if (st == CSIC_OK) {
+        (*env)->GetIntArrayRegion(env, jin, 0, nin, (jint *)pin);           /* Java heap -> pinned slot; not a critical region */
+        if ((*env)->ExceptionCheck(env)) { csic_pipeline_destroy(h->pipe); h->pipe = NULL; return NULL; }
+        st = csic_pipeline_submit(h->pipe, NULL);                           /* the fused kernel reads / writes the pinned slots */
+    }
+    if (st == CSIC_OK) st = csic_pipeline_collect(h->pipe, &pout, NULL);    /* blocks this thread only */
+    if (st != CSIC_OK) {
+        throw_for(env, st);                                                 /* reads csic_last_error() first ... */
+        if (h->pipe) { csic_pipeline_destroy(h->pipe); h->pipe = NULL; }    /* ... a frame that failed leaves no half-used slot behind */
+        return NULL;
+    }
+    return pout;
+}
+
+/* in: ARGB ints (Java int == CSIC_FMT_ARGB8888); out: ARGB or Y|Cb<<8|Cr<<16 per the plan's out_format (a planar plan: its
+ * frame buffer as frame_bytes / 4 ints -- processPlanar hands the same bytes to an Array[Byte]) */
 JNIEXPORT void JNICALL Java_jpeg_NativeBackend_00024_process(JNIEnv *env, jobject self, jlong handle, jintArray jin, jintArray jout)
 {
     (void)self;
@@ -141,21 +173,49 @@ JNIEXPORT void JNICALL Java_jpeg_NativeBackend_00024_process(JNIEnv *env, jobjec
         throw_msg(env, "java/lang/IllegalArgumentException", buf);
         return;
     }
-    int st = CSIC_OK;
-    if (!h->pipe) st = csic_pipeline_create(h->plan, 1, &h->pipe);
-    uint32_t *pin = NULL;
-    const uint32_t *pout = NULL;
-    if (st == CSIC_OK) st = csic_pipeline_acquire_input(h->pipe, &pin);
-    if (st == CSIC_OK) {
-        (*env)->GetIntArrayRegion(env, jin, 0, nin, (jint *)pin);           /* Java heap -> pinned slot; not a critical region */
-        if ((*env)->ExceptionCheck(env)) { csic_pipeline_destroy(h->pipe); h->pipe = NULL; return; }
-        st = csic_pipeline_submit(h->pipe, NULL);                           /* the fused kernel reads / writes the pinned slots */
-    }
-    if (st == CSIC_OK) st = csic_pipeline_collect(h->pipe, &pout, NULL);    /* blocks this thread only */
-    if (st != CSIC_OK) {
-        throw_for(env, st);                                                 /* reads csic_last_error() first ... */
-        if (h->pipe) { csic_pipeline_destroy(h->pipe); h->pipe = NULL; }    /* ... a frame that failed leaves no half-used slot behind */
+    const uint32_t *pout = round_trip(env, h, jin, nin);
+    if (pout) (*env)->SetIntArrayRegion(env, jout, 0, nout, (const jint *)pout);      /* pinned slot -> Java heap */
+}
+
+/* The subsampled planar format (csic.h: CSIC_FMT_PLANAR, csic_planar_layout) -- what the reference's README describes and its code
+ * never builds (README.md:35-46, ChromaSubsampler.scala:57-65).  planarLayout: the 14 fields of csic_planar_layout as an
+ * Array[Long], in declaration order; needs no device. */
+JNIEXPORT jlongArray JNICALL Java_jpeg_NativeBackend_00024_planarLayout(JNIEnv *env, jobject self, jintArray jp)
+{
+    (void)self;
+    csic_params p;
+    if (!fill(env, jp, &p)) return NULL;
+    csic_planar_layout lay;
+    int st = csic_planar_layout_of(&p, &lay);
+    if (st != CSIC_OK) { throw_for(env, st); return NULL; }
+    const jlong v[14] = {lay.y_width, lay.y_height, lay.chroma_width, lay.chroma_height, lay.module_width, lay.hold_h, lay.hold_v,
+                         lay.replay_last, lay.chroma_samples, lay.y_offset, lay.cb_offset, lay.cr_offset, lay.frame_bytes, lay.payload_bytes};
+    jlongArray r = (*env)->NewLongArray(env, 14);
+    if (!r) return NULL;                           /* OutOfMemoryError pending */
+    (*env)->SetLongArrayRegion(env, r, 0, 14, v);
+    return r;
+}
+
+/* in: ARGB ints; out: one planar frame buffer, frame_bytes bytes (planes at planarLayout's offsets).  The handle's plan must have
+ * been created with out_format = CSIC_FMT_PLANAR.  1.5 bytes per pixel cross into the Java heap for 4:2:0 instead of 4. */
+JNIEXPORT void JNICALL Java_jpeg_NativeBackend_00024_processPlanar(JNIEnv *env, jobject self, jlong handle, jintArray jin, jbyteArray jout)
+{
+    (void)self;
+    csic_jni_handle *h = (csic_jni_handle *)(intptr_t)handle;
+    if (!h || !h->plan) { throw_msg(env, "java/lang/IllegalStateException", "plan handle is closed"); return; }
+    if (!jin || !jout) { throw_msg(env, "java/lang/NullPointerException", "pixel array is null"); return; }
+    if (!h->planar) {
+        throw_msg(env, "java/lang/IllegalArgumentException", "requirement failed: processPlanar needs a plan created with out_format = CSIC_FMT_PLANAR");
         return;
     }
-    (*env)->SetIntArrayRegion(env, jout, 0, nout, (const jint *)pout);      /* pinned slot -> Java heap */
+    const jsize nin = (*env)->GetArrayLength(env, jin), nout = (*env)->GetArrayLength(env, jout);
+    if ((size_t)nin != h->in_px || (size_t)nout != 4 * h->out_px) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "requirement failed: expected %zu input pixels and %zu output bytes, got %ld and %ld",
+                 h->in_px, 4 * h->out_px, (long)nin, (long)nout);
+        throw_msg(env, "java/lang/IllegalArgumentException", buf);
+        return;
+    }
+    const uint32_t *pout = round_trip(env, h, jin, nin);
+    if (pout) (*env)->SetByteArrayRegion(env, jout, 0, nout, (const jbyte *)pout);    /* pinned slot -> Java heap */
 }

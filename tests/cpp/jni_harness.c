@@ -28,15 +28,20 @@ JNIEXPORT jlong JNICALL Java_jpeg_NativeBackend_00024_planCreate(JNIEnv *env, jo
 JNIEXPORT void JNICALL Java_jpeg_NativeBackend_00024_planDestroy(JNIEnv *env, jobject self, jlong handle);
 JNIEXPORT jintArray JNICALL Java_jpeg_NativeBackend_00024_outDims(JNIEnv *env, jobject self, jintArray jp);
 JNIEXPORT void JNICALL Java_jpeg_NativeBackend_00024_process(JNIEnv *env, jobject self, jlong handle, jintArray jin, jintArray jout);
+JNIEXPORT jlongArray JNICALL Java_jpeg_NativeBackend_00024_planarLayout(JNIEnv *env, jobject self, jintArray jp);
+JNIEXPORT void JNICALL Java_jpeg_NativeBackend_00024_processPlanar(JNIEnv *env, jobject self, jlong handle, jintArray jin, jbyteArray jout);
 
 /* ---- the fake JVM ---------------------------------------------------------------------------------------------------------*/
-enum { K_CLASS = 0x434c4153, K_INTARRAY = 0x494e5441 };
+enum { K_CLASS = 0x434c4153, K_INTARRAY = 0x494e5441, K_BYTEARRAY = 0x42595441, K_LONGARRAY = 0x4c4f4e41 };
 struct _jobject {
     int kind;
     jsize len;
-    jint *data;
+    jint *data;                 /* the elements (int[]: as such; byte[] / long[]: the same storage, elem bytes each) */
     char name[96];
+    int elem;                   /* bytes per element (0 = 4: objects built before the field existed) */
 };
+static size_t elem_of(jobject a) { return a->elem ? (size_t)a->elem : sizeof(jint); }
+static int is_array(jobject a) { return a && (a->kind == K_INTARRAY || a->kind == K_BYTEARRAY || a->kind == K_LONGARRAY); }
 
 static struct {
     int pending;
@@ -66,6 +71,17 @@ static jintArray new_int_array(jsize len)
     return o;
 }
 
+static jarray new_array(int kind, jsize len, int elem)
+{
+    jobject o = new_object(kind);
+    o->len = len;
+    o->elem = elem;
+    o->data = (jint *)calloc((size_t)(len > 0 ? len : 1), (size_t)elem);
+    if (!o->data) { perror("calloc"); exit(2); }
+    return o;
+}
+static jbyteArray new_byte_array(jsize len) { return new_array(K_BYTEARRAY, len, 1); }
+
 static void free_object(jobject o)
 {
     if (!o) return;
@@ -76,11 +92,11 @@ static void free_object(jobject o)
 /* a compacting GC between two JNI calls */
 static void move_array(jobject a)
 {
-    const size_t bytes = (size_t)(a->len > 0 ? a->len : 1) * sizeof(jint);
+    const size_t bytes = (size_t)(a->len > 0 ? a->len : 1) * elem_of(a);
     jint *fresh = (jint *)malloc(bytes);
     if (!fresh) { perror("malloc"); exit(2); }
-    memcpy(fresh, a->data, (size_t)a->len * sizeof(jint));
-    memset(a->data, 0xA5, (size_t)a->len * sizeof(jint));
+    memcpy(fresh, a->data, (size_t)a->len * elem_of(a));
+    memset(a->data, 0xA5, (size_t)a->len * elem_of(a));
     free(a->data);
     a->data = fresh;
     ++vm.moves;
@@ -125,7 +141,7 @@ static jboolean JNICALL f_ExceptionCheck(JNIEnv *env) { (void)env; return vm.pen
 static jsize JNICALL f_GetArrayLength(JNIEnv *env, jarray a)
 {
     (void)env;
-    CHECK(a && a->kind == K_INTARRAY, "GetArrayLength on a non-array");
+    CHECK(is_array(a), "GetArrayLength on a non-array");
     return a ? a->len : 0;
 }
 
@@ -148,6 +164,28 @@ static void JNICALL f_SetIntArrayRegion(JNIEnv *env, jintArray a, jsize start, j
     CHECK(!vm.pending, "JNI call with an exception pending");
     if (!a || a->kind != K_INTARRAY || start < 0 || len < 0 || start + len > a->len) { raise_vm("java/lang/ArrayIndexOutOfBoundsException", "SetIntArrayRegion"); return; }
     memcpy(a->data + start, buf, (size_t)len * sizeof(jint));
+    move_array(a);
+}
+
+static jlongArray JNICALL f_NewLongArray(JNIEnv *env, jsize len) { (void)env; return new_array(K_LONGARRAY, len, 8); }
+
+static void JNICALL f_SetByteArrayRegion(JNIEnv *env, jbyteArray a, jsize start, jsize len, const jbyte *buf)
+{
+    (void)env;
+    ++vm.region_set;
+    CHECK(!vm.pending, "JNI call with an exception pending");
+    if (!a || a->kind != K_BYTEARRAY || start < 0 || len < 0 || start + len > a->len) { raise_vm("java/lang/ArrayIndexOutOfBoundsException", "SetByteArrayRegion"); return; }
+    memcpy((jbyte *)a->data + start, buf, (size_t)len);
+    move_array(a);
+}
+
+static void JNICALL f_SetLongArrayRegion(JNIEnv *env, jlongArray a, jsize start, jsize len, const jlong *buf)
+{
+    (void)env;
+    ++vm.region_set;
+    CHECK(!vm.pending, "JNI call with an exception pending");
+    if (!a || a->kind != K_LONGARRAY || start < 0 || len < 0 || start + len > a->len) { raise_vm("java/lang/ArrayIndexOutOfBoundsException", "SetLongArrayRegion"); return; }
+    memcpy((jlong *)a->data + start, buf, (size_t)len * sizeof(jlong));
     move_array(a);
 }
 
@@ -184,7 +222,7 @@ static void JNICALL f_ReleasePrimitiveArrayCritical(JNIEnv *env, jarray a, void 
 static struct JNINativeInterface_ table;
 static JNIEnv env_value = &table;
 static JNIEnv *env = &env_value;
-static struct _jobject module_instance = {0, 0, NULL, "jpeg.NativeBackend$"};
+static struct _jobject module_instance = {0, 0, NULL, "jpeg.NativeBackend$", 0};
 
 static void vm_init(void)
 {
@@ -194,6 +232,9 @@ static void vm_init(void)
     table.ExceptionCheck = f_ExceptionCheck;
     table.GetArrayLength = f_GetArrayLength;
     table.NewIntArray = f_NewIntArray;
+    table.NewLongArray = f_NewLongArray;
+    table.SetByteArrayRegion = f_SetByteArrayRegion;
+    table.SetLongArrayRegion = f_SetLongArrayRegion;
     table.GetIntArrayRegion = f_GetIntArrayRegion;
     table.SetIntArrayRegion = f_SetIntArrayRegion;
     table.GetIntArrayElements = f_GetIntArrayElements;
@@ -290,6 +331,30 @@ static void host_checks(void)
     Java_jpeg_NativeBackend_00024_process(env, &module_instance, 0, one, one);
     CHECK(thrown("java/lang/IllegalStateException", "closed"), "process on a null handle did not throw IllegalStateException");
     free_object(one);
+    /* the planar layout is host arithmetic (csic_planar_layout_of): 64x16 4:2:0 at factor 1 -> 1024 Y bytes + 2 x 256 samples */
+    jintArray pl = pack(64, 16, 2, 0, 8, 8, 8, 1, 3, 1, 2, CSIC_ROUND_FLOOR_HW, CSIC_FMT_PLANAR, 0);
+    jlongArray lay = Java_jpeg_NativeBackend_00024_planarLayout(env, &module_instance, pl);
+    CHECK(!vm.pending && lay && lay->kind == K_LONGARRAY && lay->len == 14, "planarLayout did not return an Array[Long](14)");
+    if (lay && lay->len == 14) {
+        const jlong *v = (const jlong *)lay->data;
+        CHECK(v[0] == 64 && v[1] == 16 && v[2] == 32 && v[3] == 8 && v[4] == 64 && v[5] == 2 && v[6] == 2 && v[7] == 1 && v[8] == 256,
+              "planarLayout(64x16 4:2:0): %ld %ld %ld %ld %ld %ld %ld %ld %ld", (long)v[0], (long)v[1], (long)v[2], (long)v[3], (long)v[4], (long)v[5], (long)v[6], (long)v[7], (long)v[8]);
+        CHECK(v[9] == 0 && v[10] % 256 == 0 && v[11] % 256 == 0 && v[12] % 256 == 0 && v[13] == 1536, "planarLayout offsets / sizes: %ld %ld %ld %ld %ld",
+              (long)v[9], (long)v[10], (long)v[11], (long)v[12], (long)v[13]);
+    }
+    clear_pending();
+    free_object(lay);
+    free_object(pl);
+    jintArray badp = image_processor_params(8, 8, 3, 4, 4);
+    lay = Java_jpeg_NativeBackend_00024_planarLayout(env, &module_instance, badp);
+    CHECK(lay == NULL && thrown("java/lang/IllegalArgumentException", "requirement failed: "), "planarLayout(factor 3) did not throw");
+    free_object(badp);
+    jbyteArray nob = new_byte_array(1);
+    jintArray one2 = new_int_array(1);
+    Java_jpeg_NativeBackend_00024_processPlanar(env, &module_instance, 0, one2, nob);
+    CHECK(thrown("java/lang/IllegalStateException", "closed"), "processPlanar on a null handle did not throw IllegalStateException");
+    free_object(nob);
+    free_object(one2);
     free_object(ok);
     printf("ok: host checks (requires -> IllegalArgumentException, device errors -> RuntimeException, outDims)\n");
 }
@@ -341,6 +406,78 @@ static void golden_flow(const char *what, jintArray params, const char *in_path,
     free_object(params);
 }
 
+/* The planar format through the shim: a handle created with out_format = CSIC_FMT_PLANAR, processPlanar into an Array[Byte], against
+ * the packed YCbCr stream of a second handle with the same parameters -- the Y plane is the stream's Y bytes, the chroma planes are
+ * its Cb / Cr at the layout's sample points (hold_h x hold_v, csic.h) -- three frames through one handle. */
+static void planar_flow(const char *what, int w, int h, int a, int b, int sf, const char *in_path)
+{
+    int32_t iw, ih;
+    jintArray in = read_png(in_path, &iw, &ih);
+    CHECK(iw == w && ih == h, "%s: %s is %dx%d", what, in_path, iw, ih);
+    jintArray pp = pack(w, h, a, b, 8, 8, 8, sf, 3, 1, 2, CSIC_ROUND_FLOOR_HW, CSIC_FMT_PLANAR, 0);
+    jintArray py = pack(w, h, a, b, 8, 8, 8, sf, 3, 1, 2, CSIC_ROUND_FLOOR_HW, CSIC_FMT_YCBCR888X, 0);
+    jlongArray lay = Java_jpeg_NativeBackend_00024_planarLayout(env, &module_instance, pp);
+    CHECK(!vm.pending && lay && lay->len == 14, "%s: planarLayout failed", what);
+    clear_pending();
+    const jlong *L = (const jlong *)lay->data;
+    const int yw = (int)L[0], yh = (int)L[1], cw = (int)L[2], hh = (int)L[5], hv = (int)L[6];
+    const jlong cb_off = L[10], cr_off = L[11], frame_bytes = L[12];
+    jlong hplanar = Java_jpeg_NativeBackend_00024_planCreate(env, &module_instance, pp, 0);
+    jlong hycc = Java_jpeg_NativeBackend_00024_planCreate(env, &module_instance, py, 0);
+    CHECK(hplanar != 0 && hycc != 0 && !vm.pending, "%s: planCreate failed: %s: %s", what, vm.cls, vm.msg);
+    clear_pending();
+    if (hplanar && hycc) {
+        jintArray ycc = new_int_array(yw * yh);
+        Java_jpeg_NativeBackend_00024_process(env, &module_instance, hycc, in, ycc);
+        CHECK(!vm.pending, "%s: process (YCbCr) threw %s: %s", what, vm.cls, vm.msg);
+        clear_pending();
+        for (int rep = 0; rep < 3; ++rep) {
+            jbyteArray out = new_byte_array((jsize)frame_bytes);
+            memset(out->data, 0x5A, (size_t)frame_bytes);
+            Java_jpeg_NativeBackend_00024_processPlanar(env, &module_instance, hplanar, in, out);
+            CHECK(!vm.pending, "%s: processPlanar threw %s: %s", what, vm.cls, vm.msg);
+            clear_pending();
+            const uint8_t *bytes = (const uint8_t *)out->data;
+            long bad = 0;
+            for (int r = 0; r < yh; ++r)
+                for (int c = 0; c < yw; ++c) {
+                    const uint32_t px = (uint32_t)ycc->data[r * yw + c];
+                    bad += bytes[r * yw + c] != (px & 0xFF);
+                    if (r % hv == 0 && c % hh == 0) {
+                        const jlong k = (jlong)(r / hv) * cw + c / hh;
+                        bad += bytes[cb_off + k] != ((px >> 8) & 0xFF);
+                        bad += bytes[cr_off + k] != ((px >> 16) & 0xFF);
+                    }
+                }
+            CHECK(bad == 0, "%s (frame %d): %ld plane bytes differ from the packed YCbCr stream", what, rep, bad);
+            free_object(out);
+        }
+        /* the same frame buffer through process(): frame_bytes / 4 ints */
+        jintArray words = new_int_array((jsize)(frame_bytes / 4));
+        Java_jpeg_NativeBackend_00024_process(env, &module_instance, hplanar, in, words);
+        CHECK(!vm.pending && (((const uint8_t *)words->data)[0] == ((uint32_t)ycc->data[0] & 0xFF)), "%s: process() on a planar handle", what);
+        clear_pending();
+        free_object(words);
+        /* wrong sizes and the wrong kind of handle are require()s */
+        jbyteArray small = new_byte_array((jsize)frame_bytes - 1);
+        Java_jpeg_NativeBackend_00024_processPlanar(env, &module_instance, hplanar, in, small);
+        CHECK(thrown("java/lang/IllegalArgumentException", "requirement failed: expected"), "%s: a short byte array was accepted", what);
+        free_object(small);
+        jbyteArray full = new_byte_array((jsize)frame_bytes);
+        Java_jpeg_NativeBackend_00024_processPlanar(env, &module_instance, hycc, in, full);
+        CHECK(thrown("java/lang/IllegalArgumentException", "CSIC_FMT_PLANAR"), "%s: processPlanar on a packed plan was accepted", what);
+        free_object(full);
+        free_object(ycc);
+    }
+    Java_jpeg_NativeBackend_00024_planDestroy(env, &module_instance, hplanar);
+    Java_jpeg_NativeBackend_00024_planDestroy(env, &module_instance, hycc);
+    printf("ok: %s: %dx%d -> planes %dx%d + 2 x %ld samples (hold %dx%d) equal to the packed YCbCr stream (3 frames)\n", what, w, h, yw, yh, (long)L[8], hh, hv);
+    free_object(lay);
+    free_object(in);
+    free_object(pp);
+    free_object(py);
+}
+
 int main(int argc, char **argv)
 {
     setvbuf(stdout, NULL, _IOLBF, 0);
@@ -356,6 +493,9 @@ int main(int argc, char **argv)
         golden_flow("ImageProcessor integration flow", image_processor_params(16, 16, 2, 2, 0), argv[2], argv[3]);
         /* ImageCompressorTopApp.scala:189-190: --a 2 --b 2 --sf 2, order chroma, spatial, color on in128x128.png */
         golden_flow("ImageCompressionApp flow", pack(128, 128, 2, 2, 8, 8, 8, 2, 3, 1, 2, CSIC_ROUND_FLOOR_HW, CSIC_FMT_ARGB8888, 0), argv[4], argv[5]);
+        /* round 4: the subsampled planar format -- 4:2:0 at factor 1 (samples on even rows / columns) and at factor 2 (one per pixel) */
+        planar_flow("planar 4:2:0 sf 1", 16, 16, 2, 0, 1, argv[2]);
+        planar_flow("planar 4:2:2 sf 2", 128, 128, 2, 2, 2, argv[4]);
     }
     CHECK(vm.critical_get == 0 && vm.critical_release == 0, "the glue opened %ld critical regions", vm.critical_get);
     printf("jni calls: FindClass %ld, GetIntArrayRegion %ld, SetIntArrayRegion %ld, array moves %ld, critical regions %ld\n", vm.find_class,

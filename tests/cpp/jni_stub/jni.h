@@ -29,6 +29,8 @@ typedef jobject jclass;
 typedef jobject jthrowable;
 typedef jobject jarray;
 typedef jarray jintArray;
+typedef jarray jbyteArray;
+typedef jarray jlongArray;
 
 #define JNI_FALSE 0
 #define JNI_TRUE 1
@@ -52,15 +54,19 @@ struct JNINativeInterface_ {
     jsize (JNICALL *GetArrayLength)(JNIEnv *env, jarray array);                   /* 171 */
     void *slot_172_178[7];
     jintArray (JNICALL *NewIntArray)(JNIEnv *env, jsize len);                     /* 179 */
-    void *slot_180_186[7];
+    jlongArray (JNICALL *NewLongArray)(JNIEnv *env, jsize len);                   /* 180 */
+    void *slot_181_186[6];
     jint *(JNICALL *GetIntArrayElements)(JNIEnv *env, jintArray array, jboolean *isCopy);               /* 187 */
     void *slot_188_194[7];
     void (JNICALL *ReleaseIntArrayElements)(JNIEnv *env, jintArray array, jint *elems, jint mode);      /* 195 */
     void *slot_196_202[7];
     void (JNICALL *GetIntArrayRegion)(JNIEnv *env, jintArray array, jsize start, jsize len, jint *buf); /* 203 */
-    void *slot_204_210[7];
+    void *slot_204_207[4];
+    void (JNICALL *SetByteArrayRegion)(JNIEnv *env, jbyteArray array, jsize start, jsize len, const jbyte *buf); /* 208 */
+    void *slot_209_210[2];
     void (JNICALL *SetIntArrayRegion)(JNIEnv *env, jintArray array, jsize start, jsize len, const jint *buf); /* 211 */
-    void *slot_212_221[10];
+    void (JNICALL *SetLongArrayRegion)(JNIEnv *env, jlongArray array, jsize start, jsize len, const jlong *buf); /* 212 */
+    void *slot_213_221[9];
     void *(JNICALL *GetPrimitiveArrayCritical)(JNIEnv *env, jarray array, jboolean *isCopy);            /* 222 */
     void (JNICALL *ReleasePrimitiveArrayCritical)(JNIEnv *env, jarray array, void *carray, jint mode);  /* 223 */
     void *slot_224_227[4];
@@ -74,10 +80,13 @@ CSIC_JNI_SLOT(FindClass, 6);
 CSIC_JNI_SLOT(ThrowNew, 14);
 CSIC_JNI_SLOT(GetArrayLength, 171);
 CSIC_JNI_SLOT(NewIntArray, 179);
+CSIC_JNI_SLOT(NewLongArray, 180);
 CSIC_JNI_SLOT(GetIntArrayElements, 187);
 CSIC_JNI_SLOT(ReleaseIntArrayElements, 195);
 CSIC_JNI_SLOT(GetIntArrayRegion, 203);
+CSIC_JNI_SLOT(SetByteArrayRegion, 208);
 CSIC_JNI_SLOT(SetIntArrayRegion, 211);
+CSIC_JNI_SLOT(SetLongArrayRegion, 212);
 CSIC_JNI_SLOT(GetPrimitiveArrayCritical, 222);
 CSIC_JNI_SLOT(ReleasePrimitiveArrayCritical, 223);
 CSIC_JNI_SLOT(ExceptionCheck, 228);

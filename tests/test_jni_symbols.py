@@ -54,7 +54,7 @@ def test_jni_exports_match_the_names_the_jvm_resolves():
     for sym, (_, recv, _) in got.items():
         assert recv == ("jobject" if kind == "object" else "jclass"), (sym, recv)
     # arity and JNI types of the remaining parameters
-    jtype = {"Int": "jint", "Long": "jlong", "Array[Int]": "jintArray", "Unit": "void"}
+    jtype = {"Int": "jint", "Long": "jlong", "Array[Int]": "jintArray", "Array[Byte]": "jbyteArray", "Array[Long]": "jlongArray", "Unit": "void"}
     for name, args, ret in natives:
         sym = f"Java_{_mangle(cls)}_{_mangle(name)}"
         scala_types = [a.split(":")[1].strip() for a in args.split(",") if a.strip()]
