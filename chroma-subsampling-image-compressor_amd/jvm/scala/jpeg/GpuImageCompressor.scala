@@ -30,12 +30,24 @@ class ImageCompressorTop(
   val outWidth: Int = dims(0); val outHeight: Int = dims(1)
   private lazy val rgbPlan = NativeBackend.planCreate(packed(NativeBackend.FmtArgb), device)
   private lazy val yccPlan = NativeBackend.planCreate(packed(NativeBackend.FmtYcc), device)
+  private lazy val planarPlan = NativeBackend.planCreate(packed(NativeBackend.FmtPlanar), device)
+  /** csic_planar_layout of these parameters: plane sizes and offsets of processPlanar's buffer (no device needed). */
+  lazy val planarLayout: NativeBackend.PlanarLayout = NativeBackend.planarLayoutOf(packed(NativeBackend.FmtPlanar))
   private var opened = Set.empty[Long]
 
   /** ARGB frame in -> reconstructed ARGB frame out (DUT output through YCbCrUtils.ycbcr2rgb). */
   def process(argb: Array[Int]): Array[Int] = run(rgbPlan, argb)
   /** ARGB frame in -> io.out's PixelYCbCrBundle stream, packed Y | Cb << 8 | Cr << 16. */
   def processYCbCr(argb: Array[Int]): Array[Int] = run(yccPlan, argb)
+  /** ARGB frame in -> the subsampled planar frame buffer: one Y byte per output pixel at planarLayout.yOffset, one Cb / Cr byte per
+    * chroma SAMPLE POINT at cbOffset / crOffset (4:2:0: 1.5 bytes per pixel) -- the format the reference's README describes
+    * (README.md:35-46) and ChromaSubsampler.scala:57-65 never builds. */
+  def processPlanar(argb: Array[Int]): Array[Byte] = {
+    opened += planarPlan
+    val out = new Array[Byte](planarLayout.frameBytes.toInt)
+    NativeBackend.processPlanar(planarPlan, argb, out)
+    out
+  }
 
   private def run(plan: Long, argb: Array[Int]): Array[Int] = {
     opened += plan
