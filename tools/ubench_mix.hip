@@ -5,6 +5,8 @@
 //   8:8  copy (k_f1flat: 4 B read + 4 B written per pixel)      8:2  the headline (4 + 1)      8:3  planar forward (4 + 1.5)
 //   3:8  reconstruct of a 4:2:0 planar frame (1.5 + 4)          0:8  fill                      8:0  read only (sum kept in a lane)
 // Prints GB/s of (bytes read + bytes written) per launch, the figure roofline.achieved uses.
+// Build here, run on the GPU box:  hipcc -O3 --offload-arch=gfx950 tools/ubench_mix.hip -o tools/_bin/ubench_mix
+//                                  gpurun -- 'timeout -k 10 120 tools/_bin/ubench_mix'      (profiles/r04_ubench_mix.log)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
