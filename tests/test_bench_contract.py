@@ -2,6 +2,7 @@
 outside tests/ and smoke() that may touch the oracle), the config table and the argument surface."""
 import importlib.util
 import json
+import re
 import os
 import subprocess
 import sys
@@ -204,6 +205,22 @@ def test_committed_traffic_matches_the_checked_out_sources():
     have = kernel_source_sha256(ROOT)
     ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     assert ent["cfg4"]["source_sha256"] == have, "re-run tools/artifacts.sh profile + tools/collect_artifacts.py"
+
+
+def test_documents_name_the_source_hash_of_this_checkout():
+    """DESIGN.md and profiles/README.md say which kernel sources produced the round's artefacts: that must be this checkout's hash
+    (a csrc/ change without regenerated artefacts and updated documents fails here as well as above)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from srchash import kernel_source_sha256
+    have = kernel_source_sha256(ROOT)[:12]
+    for doc in ("DESIGN.md", os.path.join("profiles", "README.md")):
+        text = open(os.path.join(ROOT, doc), encoding="utf-8").read()
+        named = re.findall(r"source hash `([0-9a-f]{12})`", text)
+        assert named and set(named) == {have}, (doc, named, have)
+    # every profiled config of this round carries the same hash
+    ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for cfg in ("cfg4", "cfg5", "8k_444_f1", "8k_420_f1", "planar_8k_420_f1", "planar_8k_420_f1_avg", "planar_cfg4_avg", "avg_8k_420_sf2"):
+        assert ent[cfg]["source_sha256"][:12] == have, (cfg, ent[cfg]["source_sha256"][:12], have)
 
 
 def test_every_native_source_of_the_package_is_inside_the_source_hash():
